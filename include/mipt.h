@@ -1,0 +1,270 @@
+/*
+ * mipt.h -- C-ABI of the MI355X-native ray/scene path (libmipt.so).
+ *
+ * The reference (flamebrawler/Path-tracer) has no plugin / FFI interface: the
+ * path is reached through global state in one header.  The boundary below is
+ * therefore shaped after the reference's own call sites; each entry point
+ * names the reference interface it replaces
+ *   C: = reference cpu/src/cs488.h     G: = reference gpu/src/cs488.h
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative mipt_status; mipt_last_error() gives the message of
+ * the calling thread's last failure.  Nothing aborts or throws across the
+ * boundary.  The compute entry points need a gfx950 GPU and fail with
+ * MIPT_ERR_DEVICE when none is usable -- there is no CPU fallback.
+ *
+ * Images are float RGB, row-major, origin bottom-left (Image::pixel, C:199-202).
+ */
+#ifndef MIPT_H
+#define MIPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mipt_status {
+    MIPT_OK = 0,
+    MIPT_ERR_INVALID = -1, /* bad argument / malformed scene */
+    MIPT_ERR_IO = -2,      /* file missing or unparsable */
+    MIPT_ERR_DEVICE = -3,  /* no usable GPU, HIP call failed */
+    MIPT_ERR_NOMEM = -4,
+    MIPT_ERR_LIMIT = -5    /* size beyond a documented maximum */
+} mipt_status;
+
+/* enumMaterialType, C:407-412 */
+enum { MIPT_MAT_LAMBERTIAN = 0, MIPT_MAT_METAL = 1, MIPT_MAT_GLASS = 2, MIPT_MAT_LIGHT = 3 };
+
+/* Material, C:413-433 (name/glossiness dropped; texture by index) */
+typedef struct mipt_material {
+    int32_t type;
+    float eta;
+    float Ka[3], Kd[3], Ks[3];
+    float Ns;
+    int32_t tex_id; /* -1 = untextured */
+} mipt_material;
+
+/* Material::texture, 8-bit RGB, row 0 = top row of the file (C:975-982) */
+typedef struct mipt_texture {
+    const uint8_t* rgb;
+    int32_t width, height;
+} mipt_texture;
+
+/* PointLightSource, C:388-391 */
+typedef struct mipt_light {
+    float position[3];
+    float wattage[3];
+} mipt_light;
+
+/*
+ * Flat scene description: what TriangleMesh + StacklessBVH + Scene hold after
+ * Scene::preCalc (C:2027-2036), as caller-owned SoA arrays.  Replaces the
+ * per-pointer deep copy create(&deviceScene, globalScene) (G:3181,
+ * G:2291-2365, G:2442-2460, G:2667-2693).
+ *
+ * Node i: box node_min/node_max[3i..3i+2]; threaded links id_hit/id_miss
+ * (CollNode, C:1637-1639, C:1649-1659; 0 = "done"); leaf_count[i] = 0 for an
+ * interior node, else the leaf owns tri_index[leaf_first[i] ..
+ * leaf_first[i]+leaf_count[i]) in BVHNode::triList order (C:1522-1524).
+ * Triangle t: pos/nrm[9t..9t+8] (3 vertices x xyz), uv[6t..6t+5], mat_id[t].
+ * env_rgb: Image::pixels of Scene::background after Image::load's vertical
+ * flip (C:214-219); may be NULL (env_width = 0): then a lookup returns black
+ * (the reference divides by zero, C:2043).
+ */
+typedef struct mipt_scene_desc {
+    int32_t n_nodes;
+    const float* node_min;
+    const float* node_max;
+    const int32_t* id_hit;
+    const int32_t* id_miss;
+    const int32_t* leaf_first;
+    const int32_t* leaf_count;
+    int32_t n_tri_index;
+    const int32_t* tri_index;
+    int32_t n_tris;
+    const float* pos;
+    const float* nrm;
+    const float* uv;
+    const int32_t* mat_id;
+    int32_t n_materials;
+    const mipt_material* materials;
+    int32_t n_textures;
+    const mipt_texture* textures;
+    int32_t env_width, env_height;
+    const float* env_rgb;
+    int32_t n_lights;
+    const mipt_light* lights;
+} mipt_scene_desc;
+
+/* camera globals, C:65-70 + C:81-85, with the resolution made a parameter */
+typedef struct mipt_camera {
+    int32_t width, height;
+    float eye[3];
+    float lookat[3];
+    float up[3];
+    float fov_deg;   /* globalFOV = 45 */
+    float film_size; /* globalFilmSize = 0.032 */
+} mipt_camera;
+
+enum {
+    MIPT_MODE_PRIMARY = 0, /* closest-hit only: rgb = (t, tri_id, material) for debugging */
+    MIPT_MODE_DIRECT = 1,  /* Scene::Raytrace + shade, C:2200-2229, C:2402-2496 */
+    MIPT_MODE_PATH = 2     /* Scene::Pathtrace + shade_pathtrace, C:2230-2261, C:2267-2397 */
+};
+
+typedef struct mipt_render_params {
+    int32_t mode;
+    int32_t spp;           /* samples taken by this call (path mode); direct mode ignores it */
+    int32_t sample_offset; /* index of the first sample: progressive rendering continues here */
+    int32_t max_bounces;   /* extension rays per path; <0 = unbounded as in the reference */
+    uint32_t seed;
+    /* pixel partition for multi-GPU: this call renders the pixels whose
+     * tile index (tiles of tile_w x tile_h pixels, row-major over the image)
+     * satisfies tile % part_count == part_index. part_count = 1 renders all. */
+    int32_t part_index, part_count;
+    int32_t tile_w, tile_h; /* 0 = default 64 x 8 */
+} mipt_render_params;
+
+/* per-kernel-class statistics of a context, since the last reset */
+typedef struct mipt_stats {
+    uint64_t rays_closest;   /* rays given to the closest-hit kernel */
+    uint64_t rays_occluded;  /* rays given to the any-hit kernel */
+    uint64_t launches_closest, launches_occluded, launches_other;
+    double ms_closest, ms_occluded, ms_other; /* HIP-event time, only with profiling on */
+    uint64_t node_visits, tri_tests;          /* only with counting on */
+} mipt_stats;
+
+typedef struct mipt_mesh mipt_mesh;
+typedef struct mipt_image mipt_image;
+typedef struct mipt_bvh mipt_bvh;
+typedef struct mipt_scene mipt_scene;
+typedef struct mipt_ctx mipt_ctx;
+
+const char* mipt_last_error(void);
+const char* mipt_version(void);
+
+/* ---- host side: loaders, SAH-BVH build (CPU; stay on the host per north_star) ---- */
+
+/* TriangleMesh::load, C:835-923 (ParseOBJ C:1035-1312, LoadMTL C:990-1033,
+ * material typing C:849-868).  Unlike the reference, a missing file is an
+ * error code, not a crash. */
+int mipt_mesh_load_obj(const char* path, mipt_mesh** out);
+/* TriangleMesh::createSingleTriangle, C:949-970 */
+int mipt_mesh_create_single_triangle(mipt_mesh** out);
+/* a mesh from caller arrays (copied): pos/nrm 9 floats, uv 6 floats per triangle */
+int mipt_mesh_create(int32_t n_tris, const float* pos, const float* nrm, const float* uv, const int32_t* mat_id,
+                     int32_t n_materials, const mipt_material* materials, int32_t n_textures,
+                     const mipt_texture* textures, mipt_mesh** out);
+int32_t mipt_mesh_num_triangles(const mipt_mesh*);
+int32_t mipt_mesh_num_materials(const mipt_mesh*);
+int32_t mipt_mesh_num_textures(const mipt_mesh*);
+/* pointers into the mesh, valid until mipt_mesh_destroy */
+const float* mipt_mesh_positions(const mipt_mesh*);
+const float* mipt_mesh_normals(const mipt_mesh*);
+const float* mipt_mesh_texcoords(const mipt_mesh*);
+const int32_t* mipt_mesh_material_ids(const mipt_mesh*);
+const mipt_material* mipt_mesh_materials(const mipt_mesh*);
+const mipt_texture* mipt_mesh_textures(const mipt_mesh*);
+void mipt_mesh_destroy(mipt_mesh*);
+
+/* Image::load, C:204-222 (.hdr Radiance RGBE or .png; rows flipped so j = 0 is the bottom row) */
+int mipt_image_load(const char* path, mipt_image** out);
+int mipt_image_create(int32_t width, int32_t height, const float* rgb, mipt_image** out);
+int32_t mipt_image_width(const mipt_image*);
+int32_t mipt_image_height(const mipt_image*);
+const float* mipt_image_pixels(const mipt_image*);
+/* Image::save, C:223-236: clamp to [0,1], gamma 1.0, 8-bit PNG, top row first */
+int mipt_image_save_png(const char* path, int32_t width, int32_t height, const float* rgb);
+/* float output for RMSE checks (not in the reference): Radiance .hdr and .pfm */
+int mipt_image_save_hdr(const char* path, int32_t width, int32_t height, const float* rgb);
+int mipt_image_save_pfm(const char* path, int32_t width, int32_t height, const float* rgb);
+void mipt_image_destroy(mipt_image*);
+
+/* TriangleMesh::preCalc C:817-831 + BVH::build C:1562-1595 (SAH split
+ * C:1412-1558) + StacklessBVH::build links C:1645-1660 + StacklessBVH2::build
+ * links C:1713-1730.  Node numbering and leaf order equal the reference's. */
+int mipt_bvh_build(const mipt_mesh* mesh, mipt_bvh** out);
+int32_t mipt_bvh_num_nodes(const mipt_bvh*);
+int32_t mipt_bvh_num_leaves(const mipt_bvh*);
+int32_t mipt_bvh_depth(const mipt_bvh*);
+int32_t mipt_bvh_max_leaf_size(const mipt_bvh*);
+const float* mipt_bvh_node_min(const mipt_bvh*);
+const float* mipt_bvh_node_max(const mipt_bvh*);
+const int32_t* mipt_bvh_id_hit(const mipt_bvh*);
+const int32_t* mipt_bvh_id_miss(const mipt_bvh*);
+const int32_t* mipt_bvh_leaf_first(const mipt_bvh*);
+const int32_t* mipt_bvh_leaf_count(const mipt_bvh*);
+const int32_t* mipt_bvh_id_left(const mipt_bvh*);
+const int32_t* mipt_bvh_id_right(const mipt_bvh*);
+const int32_t* mipt_bvh_id_parent(const mipt_bvh*);
+const int32_t* mipt_bvh_id_sibling(const mipt_bvh*);
+const int32_t* mipt_bvh_tri_index(const mipt_bvh*);
+void mipt_bvh_destroy(mipt_bvh*);
+
+/* Scene::addObject / addLight / background + preCalc, C:2020-2036: fills a
+ * mipt_scene_desc that points INTO mesh, bvh and env (keep them alive while
+ * the desc is used).  env may be NULL. */
+int mipt_scene_desc_fill(const mipt_mesh* mesh, const mipt_bvh* bvh, const mipt_image* env, const mipt_light* lights,
+                         int32_t n_lights, mipt_scene_desc* out);
+
+/* ---- device side ---- */
+
+/* Validates and COPIES the description (caller may free its arrays at once). */
+int mipt_scene_create(const mipt_scene_desc* desc, mipt_scene** out);
+void mipt_scene_destroy(mipt_scene*);
+
+/* One context per GPU: uploads the scene as ONE hipMalloc'd arena of flat
+ * SoA sections (replaces create(&deviceScene, globalScene), G:3181).  A
+ * context is not thread-safe; different contexts may be driven from
+ * different threads or processes.  stream: a hipStream_t, or NULL for a
+ * stream the context creates. */
+int mipt_context_create(const mipt_scene* scene, int device, void* stream, mipt_ctx** out);
+void mipt_context_destroy(mipt_ctx*);
+size_t mipt_context_arena_bytes(const mipt_ctx*);
+
+/* Scene::intersect, C:2070-2085, over a batch of caller-supplied rays with
+ * the threaded traversal StacklessBVH::intersect, C:1661-1683, and
+ * raytraceTriangle, C:777-813.  HOST pointers: ray_o/ray_d 3 floats per ray.
+ * Outputs (any may be NULL): tri_id (-1 = miss), t (FLT_MAX on miss),
+ * bary = (beta, gamma), hitrec = HitInfo as 10 floats {t, P3, N3, T2, material}
+ * (C:510-517; material = index, -1 on miss). */
+int mipt_trace(mipt_ctx* ctx, const float* ray_o, const float* ray_d, size_t n, float tmin, float tmax,
+               int32_t* tri_id, float* t, float* bary, float* hitrec);
+/* the same with DEVICE pointers on the context's stream; no synchronisation.
+ * rays: n x {o.xyz, tmin, d.xyz, tmax} (32 B); hits: n x {tri_id, t, beta, gamma} (16 B). */
+int mipt_trace_device(mipt_ctx* ctx, const void* rays_dev, size_t n, void* hits_dev);
+/* StacklessBVH::isHit, C:1684-1705 (any-hit), as Scene::isHit uses it for
+ * shadow rays, C:2056-2068.  HOST pointers; per-ray tmin/tmax. */
+int mipt_occluded(mipt_ctx* ctx, const float* ray_o, const float* ray_d, const float* tmin, const float* tmax,
+                  size_t n, uint8_t* occluded);
+/* Scene::eyeRay, C:2183-2197, for pixels [first, first+count) in row-major
+ * (j, i) order; HOST outputs. Computed on the GPU by the generate kernel. */
+int mipt_eye_rays(mipt_ctx* ctx, const mipt_camera* cam, size_t first, size_t count, float* ray_o, float* ray_d);
+/* Scene::getBackground, C:2038-2053; HOST pointers. */
+int mipt_background(mipt_ctx* ctx, const float* dir, size_t n, float* rgb);
+
+/* Scene::Raytrace / Scene::Pathtrace (C:2200-2261) for this call's pixel
+ * partition.  accum_dev / rgb_dev are DEVICE buffers of width*height*3
+ * floats (AccumulationBuffer / FrameBuffer, C:240-243); pixels outside the
+ * partition are not touched.  accum_dev must be zero before sample 0 and is
+ * carried by the caller between calls (progressive rendering); it may be
+ * NULL in primary/direct mode.  Asynchronous on the context's stream. */
+int mipt_render_device(mipt_ctx* ctx, const mipt_camera* cam, const mipt_render_params* params, float* accum_dev,
+                       float* rgb_dev);
+/* convenience: whole image to a HOST buffer (allocates, renders, copies back, synchronises) */
+int mipt_render(mipt_ctx* ctx, const mipt_camera* cam, const mipt_render_params* params, float* rgb_host);
+
+int mipt_context_synchronize(mipt_ctx* ctx);
+/* profiling: HIP events around every kernel launch on the context's stream */
+int mipt_context_set_profiling(mipt_ctx* ctx, int enabled);
+/* counting: the traversal kernels also count node visits and triangle tests */
+int mipt_context_set_counting(mipt_ctx* ctx, int enabled);
+int mipt_context_get_stats(mipt_ctx* ctx, mipt_stats* out);
+int mipt_context_reset_stats(mipt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPT_H */
