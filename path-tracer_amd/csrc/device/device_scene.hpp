@@ -1,0 +1,47 @@
+// device_scene.hpp -- layout of the scene arena in HBM and the records the
+// kernels exchange.  One hipMalloc holds every section (256-B aligned):
+//
+//   nodes     2 x float4 per BVH node (32 B):
+//               lo = {min.xyz, bits(idMiss)}
+//               hi = {max.xyz, bits(link)}   link > 0: idHit of an interior node
+//                                            link < 0: leaf, first leaf triangle = ~link,
+//                                                      and its idHit == idMiss
+//             (threaded links of StacklessBVH, reference cs488.h:1637-1659; 0 = done)
+//   leafTris  3 x float4 per triangle reference (48 B), in leaf (triList) order:
+//               {p0.xyz, bits(original triangle id)}
+//               {p0-p1,  bits(1 if last triangle of its leaf)}
+//               {p0-p2,  0}
+//             the two edge vectors are the first two operands of the
+//             reference's Cramer test (cs488.h:782-783), rounded once on the
+//             host exactly as the reference rounds them per test
+//   triAttr   7 x float4 per triangle (112 B), original order, for shading only:
+//               p0 p1 p2 n0 n1 n2 (18 floats) uv0 uv1 uv2 (6) bits(material id) pad
+//   materials 4 x float4 per material: {type, eta, Ns, bits(texel offset or -1)}
+//               {Kd.xyz, bits(texW)} {Ks.xyz, bits(texH)} {Ka.xyz, 0}
+//   texels    8-bit RGB, row 0 = top row of the file
+//   env       float3 per pixel, row 0 = bottom (after Image::load's flip)
+//   lights    2 x float4 per light: {position, 0} {wattage, 0}
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ptd {
+
+struct DevScene {
+    const float4* nodes;
+    const float4* leafTris;
+    const float4* triAttr;
+    const float4* materials;
+    const unsigned char* texels;
+    const float* env;
+    const float4* lights;
+    int nNodes, nLeafTris, nTris, nMaterials, envW, envH, nLights;
+};
+
+// ray record, 32 B: {o.xyz, tmin} {d.xyz, tmax}
+// hit record, 16 B: {bits(tri_id or -1), t, beta, gamma}
+
+constexpr int kBlock = 256;
+
+}  // namespace ptd
