@@ -120,11 +120,12 @@ typedef struct mipt_render_params {
     int32_t sample_offset; /* index of the first sample: progressive rendering continues here */
     int32_t max_bounces;   /* extension rays per path; <0 = unbounded as in the reference */
     uint32_t seed;
-    /* pixel partition for multi-GPU: this call renders the pixels whose
-     * tile index (tiles of tile_w x tile_h pixels, row-major over the image)
-     * satisfies tile % part_count == part_index. part_count = 1 renders all. */
+    /* pixel partition for multi-GPU: the image is cut into tiles of
+     * tile_w x tile_h pixels; this call renders tile (tx, ty) iff
+     * (tx + 3*ty) % part_count == part_index (diagonal interleave, so sky and
+     * geometry spread over the parts). part_count <= 1 renders all. */
     int32_t part_index, part_count;
-    int32_t tile_w, tile_h; /* 0 = default 64 x 8 */
+    int32_t tile_w, tile_h; /* multiples of 8; 0 = default 64 x 8 */
 } mipt_render_params;
 
 /* per-kernel-class statistics of a context, since the last reset */

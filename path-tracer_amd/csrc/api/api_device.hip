@@ -1,0 +1,651 @@
+// api_device.hip -- the device half of the C-ABI (include/mipt.h): scene
+// validation and copy, the one-arena upload, and the entry points that drive
+// the HIP kernels.  There is no CPU path here: without a usable GPU every
+// compute entry point fails with MIPT_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../device/kernels.hpp"
+#include "../device/shading.hpp"
+#include "../pt/host.hpp"
+
+using namespace ptd;
+
+namespace {
+
+unsigned pcg_hash_host(unsigned v) {
+    const unsigned state = v * 747796405u + 2891336453u;
+    const unsigned word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pt::set_error(std::string(#expr) + " failed: " + hipGetErrorString(e_));           \
+            return MIPT_ERR_DEVICE;                                                            \
+        }                                                                                      \
+    } while (0)
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// host copy of a validated scene
+struct mipt_scene {
+    std::vector<float4> nodes, leafTris, triAttr, materials, lights;
+    std::vector<unsigned char> texels;
+    std::vector<float> env;
+    int nNodes = 0, nLeafTris = 0, nTris = 0, nMaterials = 0, envW = 0, envH = 0, nLights = 0;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return MIPT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        return MIPT_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+    int cls;
+};
+
+struct mipt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    void* arena = nullptr;
+    size_t arenaBytes = 0;
+    DevScene ds{};
+    // scratch of the host-pointer entry points
+    DevBuf sRays, sHits, sOut, sAux, sAux2;
+    // integrator state
+    DevBuf pathMem, tileMem, frameMem;
+    PathBuffers pb{};
+    std::vector<int> tileKey;
+    int nOwnedTiles = 0;
+    // stats
+    bool profiling = false, counting = false;
+    unsigned long long* dTotals = nullptr;  // [0] ext rays [1] shadow rays [2..3] closest visits/tests [4..5] occluded
+    mipt_stats acc{};
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> freeEvents;
+};
+
+namespace {
+
+int fail(int code, const std::string& msg) {
+    pt::set_error(msg);
+    return code;
+}
+
+struct Timer {
+    mipt_ctx* c;
+    hipEvent_t a = nullptr, b = nullptr;
+    int cls;
+    Timer(mipt_ctx* ctx, int klass) : c(ctx), cls(klass) {
+        if (!c->profiling) return;
+        a = take();
+        b = take();
+        if (a && b) (void)hipEventRecord(a, c->stream);
+    }
+    hipEvent_t take() {
+        if (!c->freeEvents.empty()) {
+            hipEvent_t e = c->freeEvents.back();
+            c->freeEvents.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    ~Timer() {
+        if (!c->profiling || !a || !b) return;
+        (void)hipEventRecord(b, c->stream);
+        c->timed.push_back(TimedLaunch{a, b, cls});
+    }
+};
+
+void count_launch(mipt_ctx* c, int cls) {
+    if (cls == 0) c->acc.launches_closest++;
+    else if (cls == 1) c->acc.launches_occluded++;
+    else c->acc.launches_other++;
+}
+
+void trace_closest(mipt_ctx* c, const float4* rays, const int* index, const unsigned* countPtr, size_t nMax,
+                   float4* hits) {
+    Timer t(c, 0);
+    count_launch(c, 0);
+    launch_trace_closest(c->stream, c->ds, rays, index, countPtr, nMax, hits, c->counting ? c->dTotals + 2 : nullptr);
+}
+void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, const unsigned* countPtr, size_t nMax,
+                    unsigned char* occ) {
+    Timer t(c, 1);
+    count_launch(c, 1);
+    launch_trace_occluded(c->stream, c->ds, rays, target, countPtr, nMax, occ, c->counting ? c->dTotals + 4 : nullptr);
+}
+
+int make_camera(const mipt_camera* cam, CameraDev& out) {
+    if (!cam || cam->width <= 0 || cam->height <= 0 || cam->width > 32768 || cam->height > 32768)
+        return fail(MIPT_ERR_INVALID, "camera: bad resolution");
+    out.width = cam->width;
+    out.height = cam->height;
+    out.eye = pt::vec3{cam->eye[0], cam->eye[1], cam->eye[2]};
+    out.up = pt::normalize(pt::vec3{cam->up[0], cam->up[1], cam->up[2]});                                // C:83
+    out.viewDir = pt::normalize(pt::vec3{cam->lookat[0], cam->lookat[1], cam->lookat[2]} - out.eye);      // C:2609
+    out.aspect = (float)(cam->width / (float)cam->height);                                               // C:65
+    out.filmSize = cam->film_size;                                                                       // C:69
+    const float DegToRad = kPI / 180.0f;                                                                 // C:51
+    out.distanceToFilm = cam->film_size / (2.0f * tanf(cam->fov_deg * DegToRad * 0.5f));                 // C:70
+    return MIPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
+    if (!d || !out) return fail(MIPT_ERR_INVALID, "mipt_scene_create: null argument");
+    if (d->n_nodes <= 0 || d->n_tris <= 0 || d->n_tri_index <= 0 || !d->node_min || !d->node_max || !d->id_hit ||
+        !d->id_miss || !d->leaf_first || !d->leaf_count || !d->tri_index || !d->pos || !d->nrm || !d->uv || !d->mat_id)
+        return fail(MIPT_ERR_INVALID, "mipt_scene_create: missing geometry arrays");
+    if (d->n_materials <= 0 || !d->materials) return fail(MIPT_ERR_INVALID, "mipt_scene_create: no materials");
+    if (d->n_lights < 0 || d->n_lights > kMaxLights || (d->n_lights && !d->lights))
+        return fail(MIPT_ERR_LIMIT, "mipt_scene_create: at most 16 point lights");
+    if (d->n_textures < 0 || (d->n_textures && !d->textures)) return fail(MIPT_ERR_INVALID, "bad textures");
+    if ((d->env_width > 0) != (d->env_height > 0) || (d->env_width > 0 && !d->env_rgb))
+        return fail(MIPT_ERR_INVALID, "bad environment image");
+    try {
+        mipt_scene* s = new mipt_scene();
+        const int n = d->n_nodes;
+        // Link validation.  Preorder threading means every link points forward
+        // (or to 0 = done); enforcing that here guarantees that every walk on
+        // the GPU terminates, whatever the caller passed in.
+        s->nodes.resize((size_t)2 * n);
+        s->leafTris.resize((size_t)3 * d->n_tri_index);
+        std::vector<char> covered((size_t)d->n_tri_index, 0);
+        for (int i = 0; i < n; i++) {
+            const int miss = d->id_miss[i], hit = d->id_hit[i];
+            const int cnt = d->leaf_count[i], first = d->leaf_first[i];
+            if (!(miss == 0 || (miss > i && miss < n))) { delete s; return fail(MIPT_ERR_INVALID, "id_miss must point forward or be 0"); }
+            int link;
+            if (cnt > 0) {
+                if (hit != miss) { delete s; return fail(MIPT_ERR_INVALID, "a leaf's id_hit must equal its id_miss"); }
+                if (first < 0 || (long long)first + cnt > d->n_tri_index) { delete s; return fail(MIPT_ERR_INVALID, "leaf range out of tri_index"); }
+                link = ~first;
+                for (int k = 0; k < cnt; k++) {
+                    const int j = first + k;
+                    const int t = d->tri_index[j];
+                    if (t < 0 || t >= d->n_tris || covered[j]) { delete s; return fail(MIPT_ERR_INVALID, "bad tri_index entry"); }
+                    covered[j] = 1;
+                    const float* p = d->pos + (size_t)9 * t;
+                    const pt::vec3 p0{p[0], p[1], p[2]}, p1{p[3], p[4], p[5]}, p2{p[6], p[7], p[8]};
+                    const pt::vec3 a = p0 - p1, b = p0 - p2;  // C:782-783
+                    s->leafTris[(size_t)3 * j] = make_float4(p0.x, p0.y, p0.z, __builtin_bit_cast(float, t));
+                    s->leafTris[(size_t)3 * j + 1] = make_float4(a.x, a.y, a.z, __builtin_bit_cast(float, (int)(k == cnt - 1)));
+                    s->leafTris[(size_t)3 * j + 2] = make_float4(b.x, b.y, b.z, 0.0f);
+                }
+            } else {
+                if (!(hit > i && hit < n)) { delete s; return fail(MIPT_ERR_INVALID, "an interior node's id_hit must point forward"); }
+                link = hit;
+            }
+            s->nodes[(size_t)2 * i] = make_float4(d->node_min[3 * i], d->node_min[3 * i + 1], d->node_min[3 * i + 2],
+                                                  __builtin_bit_cast(float, miss));
+            s->nodes[(size_t)2 * i + 1] = make_float4(d->node_max[3 * i], d->node_max[3 * i + 1], d->node_max[3 * i + 2],
+                                                      __builtin_bit_cast(float, link));
+        }
+        for (char cv : covered)
+            if (!cv) { delete s; return fail(MIPT_ERR_INVALID, "tri_index entry not owned by any leaf"); }
+        // textures -> one byte pool
+        std::vector<int> texOfs((size_t)d->n_textures, 0);
+        for (int i = 0; i < d->n_textures; i++) {
+            const mipt_texture& t = d->textures[i];
+            if (!t.rgb || t.width <= 0 || t.height <= 0) { delete s; return fail(MIPT_ERR_INVALID, "empty texture"); }
+            texOfs[i] = (int)s->texels.size();
+            s->texels.insert(s->texels.end(), t.rgb, t.rgb + (size_t)3 * t.width * t.height);
+        }
+        s->materials.resize((size_t)4 * d->n_materials);
+        for (int i = 0; i < d->n_materials; i++) {
+            const mipt_material& m = d->materials[i];
+            if (m.tex_id >= d->n_textures) { delete s; return fail(MIPT_ERR_INVALID, "material tex_id out of range"); }
+            const int ofs = m.tex_id >= 0 ? texOfs[m.tex_id] : -1;
+            const int tw = m.tex_id >= 0 ? d->textures[m.tex_id].width : 0;
+            const int th = m.tex_id >= 0 ? d->textures[m.tex_id].height : 0;
+            s->materials[(size_t)4 * i] = make_float4(__builtin_bit_cast(float, (int)m.type), m.eta, m.Ns, __builtin_bit_cast(float, ofs));
+            s->materials[(size_t)4 * i + 1] = make_float4(m.Kd[0], m.Kd[1], m.Kd[2], __builtin_bit_cast(float, tw));
+            s->materials[(size_t)4 * i + 2] = make_float4(m.Ks[0], m.Ks[1], m.Ks[2], __builtin_bit_cast(float, th));
+            s->materials[(size_t)4 * i + 3] = make_float4(m.Ka[0], m.Ka[1], m.Ka[2], 0.0f);
+        }
+        s->triAttr.resize((size_t)7 * d->n_tris);
+        for (int t = 0; t < d->n_tris; t++) {
+            if (d->mat_id[t] < 0 || d->mat_id[t] >= d->n_materials) { delete s; return fail(MIPT_ERR_INVALID, "mat_id out of range"); }
+            float f[28];
+            memcpy(f, d->pos + (size_t)9 * t, 36);
+            memcpy(f + 9, d->nrm + (size_t)9 * t, 36);
+            memcpy(f + 18, d->uv + (size_t)6 * t, 24);
+            const int mid = d->mat_id[t];
+            memcpy(f + 24, &mid, 4);
+            f[25] = f[26] = f[27] = 0.0f;
+            memcpy(&s->triAttr[(size_t)7 * t], f, sizeof f);
+        }
+        if (d->env_width > 0) s->env.assign(d->env_rgb, d->env_rgb + (size_t)3 * d->env_width * d->env_height);
+        s->lights.resize((size_t)2 * d->n_lights);
+        for (int i = 0; i < d->n_lights; i++) {
+            const mipt_light& l = d->lights[i];
+            s->lights[(size_t)2 * i] = make_float4(l.position[0], l.position[1], l.position[2], 0.0f);
+            s->lights[(size_t)2 * i + 1] = make_float4(l.wattage[0], l.wattage[1], l.wattage[2], 0.0f);
+        }
+        s->nNodes = n; s->nLeafTris = d->n_tri_index; s->nTris = d->n_tris; s->nMaterials = d->n_materials;
+        s->envW = d->env_width; s->envH = d->env_height; s->nLights = d->n_lights;
+        *out = s;
+        return MIPT_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(MIPT_ERR_NOMEM, "out of host memory");
+    }
+}
+
+void mipt_scene_destroy(mipt_scene* s) { delete s; }
+
+int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx** out) {
+    if (!s || !out) return fail(MIPT_ERR_INVALID, "mipt_context_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MIPT_ERR_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(MIPT_ERR_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    mipt_ctx* c = new mipt_ctx();
+    c->device = device;
+    if (stream) c->stream = (hipStream_t)stream;
+    else {
+        if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(MIPT_ERR_DEVICE, "hipStreamCreate failed"); }
+        c->ownStream = true;
+    }
+    // one arena, 256-B aligned sections
+    const size_t szNodes = align256(s->nodes.size() * sizeof(float4));
+    const size_t szLeaf = align256(s->leafTris.size() * sizeof(float4));
+    const size_t szAttr = align256(s->triAttr.size() * sizeof(float4));
+    const size_t szMat = align256(s->materials.size() * sizeof(float4));
+    const size_t szTex = align256(s->texels.size() + 4);
+    const size_t szEnv = align256(s->env.size() * sizeof(float) + 4);
+    const size_t szLights = align256(s->lights.size() * sizeof(float4) + 16);
+    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights;
+    std::vector<unsigned char> stage(total, 0);
+    size_t o = 0;
+    const size_t oNodes = o; memcpy(&stage[o], s->nodes.data(), s->nodes.size() * sizeof(float4)); o += szNodes;
+    const size_t oLeaf = o; memcpy(&stage[o], s->leafTris.data(), s->leafTris.size() * sizeof(float4)); o += szLeaf;
+    const size_t oAttr = o; memcpy(&stage[o], s->triAttr.data(), s->triAttr.size() * sizeof(float4)); o += szAttr;
+    const size_t oMat = o; memcpy(&stage[o], s->materials.data(), s->materials.size() * sizeof(float4)); o += szMat;
+    const size_t oTex = o; if (!s->texels.empty()) memcpy(&stage[o], s->texels.data(), s->texels.size()); o += szTex;
+    const size_t oEnv = o; if (!s->env.empty()) memcpy(&stage[o], s->env.data(), s->env.size() * sizeof(float)); o += szEnv;
+    const size_t oLights = o; if (!s->lights.empty()) memcpy(&stage[o], s->lights.data(), s->lights.size() * sizeof(float4));
+    if (hipMalloc(&c->arena, total) != hipSuccess) { mipt_context_destroy(c); return fail(MIPT_ERR_DEVICE, "hipMalloc(arena) failed"); }
+    c->arenaBytes = total;
+    if (hipMemcpy(c->arena, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+        mipt_context_destroy(c);
+        return fail(MIPT_ERR_DEVICE, "arena upload failed");
+    }
+    unsigned char* base = (unsigned char*)c->arena;
+    c->ds.nodes = (const float4*)(base + oNodes);
+    c->ds.leafTris = (const float4*)(base + oLeaf);
+    c->ds.triAttr = (const float4*)(base + oAttr);
+    c->ds.materials = (const float4*)(base + oMat);
+    c->ds.texels = base + oTex;
+    c->ds.env = (const float*)(base + oEnv);
+    c->ds.lights = (const float4*)(base + oLights);
+    c->ds.nNodes = s->nNodes; c->ds.nLeafTris = s->nLeafTris; c->ds.nTris = s->nTris; c->ds.nMaterials = s->nMaterials;
+    c->ds.envW = s->envW; c->ds.envH = s->envH; c->ds.nLights = s->nLights;
+    if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->dTotals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        mipt_context_destroy(c);
+        return fail(MIPT_ERR_DEVICE, "hipMalloc(stats) failed");
+    }
+    *out = c;
+    return MIPT_OK;
+}
+
+void mipt_context_destroy(mipt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : c->freeEvents) (void)hipEventDestroy(e);
+    c->sRays.release(); c->sHits.release(); c->sOut.release(); c->sAux.release(); c->sAux2.release();
+    c->pathMem.release(); c->tileMem.release(); c->frameMem.release();
+    if (c->dTotals) (void)hipFree(c->dTotals);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+size_t mipt_context_arena_bytes(const mipt_ctx* c) { return c ? c->arenaBytes : 0; }
+
+int mipt_context_synchronize(mipt_ctx* c) {
+    if (!c) return fail(MIPT_ERR_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MIPT_OK;
+}
+int mipt_context_set_profiling(mipt_ctx* c, int enabled) {
+    if (!c) return fail(MIPT_ERR_INVALID, "null context");
+    c->profiling = enabled != 0;
+    return MIPT_OK;
+}
+int mipt_context_set_counting(mipt_ctx* c, int enabled) {
+    if (!c) return fail(MIPT_ERR_INVALID, "null context");
+    c->counting = enabled != 0;
+    return MIPT_OK;
+}
+
+static int drain_timers(mipt_ctx* c) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& t : c->timed) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            if (t.cls == 0) c->acc.ms_closest += ms;
+            else if (t.cls == 1) c->acc.ms_occluded += ms;
+            else c->acc.ms_other += ms;
+        }
+        c->freeEvents.push_back(t.a);
+        c->freeEvents.push_back(t.b);
+    }
+    c->timed.clear();
+    return MIPT_OK;
+}
+
+int mipt_context_get_stats(mipt_ctx* c, mipt_stats* out) {
+    if (!c || !out) return fail(MIPT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = drain_timers(c);
+    if (rc != MIPT_OK) return rc;
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpy(h, c->dTotals, sizeof h, hipMemcpyDeviceToHost));
+    *out = c->acc;
+    out->rays_closest += h[0];
+    out->rays_occluded += h[1];
+    out->node_visits = h[2] + h[4];
+    out->tri_tests = h[3] + h[5];
+    return MIPT_OK;
+}
+int mipt_context_reset_stats(mipt_ctx* c) {
+    if (!c) return fail(MIPT_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = drain_timers(c);
+    if (rc != MIPT_OK) return rc;
+    memset(&c->acc, 0, sizeof c->acc);
+    HIP_TRY(hipMemset(c->dTotals, 0, 8 * sizeof(unsigned long long)));
+    return MIPT_OK;
+}
+
+int mipt_trace_device(mipt_ctx* c, const void* rays_dev, size_t n, void* hits_dev) {
+    if (!c || (n && (!rays_dev || !hits_dev))) return fail(MIPT_ERR_INVALID, "mipt_trace_device: null argument");
+    if (n > 0x7fffffffu) return fail(MIPT_ERR_LIMIT, "mipt_trace_device: at most 2^31-1 rays per call");
+    if (n == 0) return MIPT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    trace_closest(c, (const float4*)rays_dev, nullptr, nullptr, n, (float4*)hits_dev);
+    c->acc.rays_closest += n;
+    HIP_TRY(hipGetLastError());
+    return MIPT_OK;
+}
+
+int mipt_trace(mipt_ctx* c, const float* ray_o, const float* ray_d, size_t n, float tmin, float tmax, int32_t* tri_id,
+               float* t, float* bary, float* hitrec) {
+    if (!c || (n && (!ray_o || !ray_d))) return fail(MIPT_ERR_INVALID, "mipt_trace: null argument");
+    if (n > 0x7fffffffu) return fail(MIPT_ERR_LIMIT, "mipt_trace: at most 2^31-1 rays per call");
+    if (n == 0) return MIPT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float4> rays((size_t)2 * n);
+    for (size_t i = 0; i < n; i++) {
+        rays[2 * i] = make_float4(ray_o[3 * i], ray_o[3 * i + 1], ray_o[3 * i + 2], tmin);
+        rays[2 * i + 1] = make_float4(ray_d[3 * i], ray_d[3 * i + 1], ray_d[3 * i + 2], tmax);
+    }
+    int rc;
+    if ((rc = c->sRays.ensure(rays.size() * sizeof(float4))) != MIPT_OK) return rc;
+    if ((rc = c->sHits.ensure(n * sizeof(float4))) != MIPT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->sRays.p, rays.data(), rays.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    trace_closest(c, (const float4*)c->sRays.p, nullptr, nullptr, n, (float4*)c->sHits.p);
+    c->acc.rays_closest += n;
+    std::vector<float4> hits(n);
+    HIP_TRY(hipMemcpyAsync(hits.data(), c->sHits.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (hitrec) {
+        if ((rc = c->sOut.ensure(n * 10 * sizeof(float))) != MIPT_OK) return rc;
+        {
+            Timer tm(c, 2);
+            count_launch(c, 2);
+            launch_resolve_hits(c->stream, c->ds, (const float4*)c->sRays.p, (const float4*)c->sHits.p, n, (float*)c->sOut.p);
+        }
+        HIP_TRY(hipMemcpyAsync(hitrec, c->sOut.p, n * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    for (size_t i = 0; i < n; i++) {
+        int id;
+        memcpy(&id, &hits[i].x, 4);
+        if (tri_id) tri_id[i] = id;
+        if (t) t[i] = hits[i].y;
+        if (bary) { bary[2 * i] = hits[i].z; bary[2 * i + 1] = hits[i].w; }
+    }
+    return MIPT_OK;
+}
+
+int mipt_occluded(mipt_ctx* c, const float* ray_o, const float* ray_d, const float* tmin, const float* tmax, size_t n,
+                  uint8_t* occluded) {
+    if (!c || (n && (!ray_o || !ray_d || !tmin || !tmax || !occluded))) return fail(MIPT_ERR_INVALID, "mipt_occluded: null argument");
+    if (n > 0x7fffffffu) return fail(MIPT_ERR_LIMIT, "mipt_occluded: at most 2^31-1 rays per call");
+    if (n == 0) return MIPT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float4> rays((size_t)2 * n);
+    for (size_t i = 0; i < n; i++) {
+        rays[2 * i] = make_float4(ray_o[3 * i], ray_o[3 * i + 1], ray_o[3 * i + 2], tmin[i]);
+        rays[2 * i + 1] = make_float4(ray_d[3 * i], ray_d[3 * i + 1], ray_d[3 * i + 2], tmax[i]);
+    }
+    int rc;
+    if ((rc = c->sRays.ensure(rays.size() * sizeof(float4))) != MIPT_OK) return rc;
+    if ((rc = c->sAux.ensure(n)) != MIPT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->sRays.p, rays.data(), rays.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->sAux.p, 0, n, c->stream));
+    trace_occluded(c, (const float4*)c->sRays.p, nullptr, nullptr, n, (unsigned char*)c->sAux.p);
+    c->acc.rays_occluded += n;
+    HIP_TRY(hipMemcpyAsync(occluded, c->sAux.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return MIPT_OK;
+}
+
+int mipt_eye_rays(mipt_ctx* c, const mipt_camera* cam, size_t first, size_t count, float* ray_o, float* ray_d) {
+    if (!c || !cam || (count && (!ray_o || !ray_d))) return fail(MIPT_ERR_INVALID, "mipt_eye_rays: null argument");
+    CameraDev cd;
+    int rc = make_camera(cam, cd);
+    if (rc != MIPT_OK) return rc;
+    if (first + count > (size_t)cam->width * cam->height) return fail(MIPT_ERR_INVALID, "mipt_eye_rays: pixel range outside the image");
+    if (count > 0x7fffffffu) return fail(MIPT_ERR_LIMIT, "mipt_eye_rays: too many rays");
+    if (count == 0) return MIPT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = c->sRays.ensure(count * 2 * sizeof(float4))) != MIPT_OK) return rc;
+    {
+        Timer tm(c, 2);
+        count_launch(c, 2);
+        launch_eye_rays(c->stream, cd, first, count, (float4*)c->sRays.p);
+    }
+    std::vector<float4> rays(count * 2);
+    HIP_TRY(hipMemcpyAsync(rays.data(), c->sRays.p, rays.size() * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    for (size_t i = 0; i < count; i++) {
+        ray_o[3 * i] = rays[2 * i].x; ray_o[3 * i + 1] = rays[2 * i].y; ray_o[3 * i + 2] = rays[2 * i].z;
+        ray_d[3 * i] = rays[2 * i + 1].x; ray_d[3 * i + 1] = rays[2 * i + 1].y; ray_d[3 * i + 2] = rays[2 * i + 1].z;
+    }
+    return MIPT_OK;
+}
+
+int mipt_background(mipt_ctx* c, const float* dir, size_t n, float* rgb) {
+    if (!c || (n && (!dir || !rgb))) return fail(MIPT_ERR_INVALID, "mipt_background: null argument");
+    if (n > 0x7fffffffu / 3) return fail(MIPT_ERR_LIMIT, "mipt_background: too many directions");
+    if (n == 0) return MIPT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->sAux.ensure(n * 3 * sizeof(float))) != MIPT_OK) return rc;
+    if ((rc = c->sAux2.ensure(n * 3 * sizeof(float))) != MIPT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->sAux.p, dir, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    {
+        Timer tm(c, 2);
+        count_launch(c, 2);
+        launch_background(c->stream, c->ds, (const float*)c->sAux.p, n, (float*)c->sAux2.p);
+    }
+    HIP_TRY(hipMemcpyAsync(rgb, c->sAux2.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return MIPT_OK;
+}
+
+// carve the integrator's buffers out of one allocation
+static int ensure_path_buffers(mipt_ctx* c, size_t cap) {
+    const int nl = c->ds.nLights > 0 ? c->ds.nLights : 1;
+    if (c->pb.capacity >= cap && c->pb.nLights == nl) return MIPT_OK;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
+    const size_t f4 = sizeof(float4);
+    const size_t oRays = take(2 * cap * f4), oHit = take(cap * f4), oMult = take(cap * f4), oCnst = take(cap * f4);
+    const size_t oPend = take(cap * f4), oHm = take(cap * f4), oVP = take(cap * f4), oVN = take(cap * f4), oVT = take(cap * f4);
+    const size_t oContrib = take(cap * nl * f4), oOcc = take(cap * nl), oKs = take(cap * 6 * f4), oPix = take(cap * 4);
+    const size_t oQ0 = take(cap * 4), oQ1 = take(cap * 4), oQA = take(cap * 4);
+    const size_t oSh = take(2 * cap * nl * f4), oShT = take(cap * nl * 4), oCnt = take((size_t)kMaxIter * 4 * 4);
+    int rc = c->pathMem.ensure(o);
+    if (rc != MIPT_OK) { c->pb.capacity = 0; return rc; }
+    unsigned char* b = (unsigned char*)c->pathMem.p;
+    PathBuffers& pb = c->pb;
+    pb.capacity = cap; pb.nLights = nl;
+    pb.rays = (float4*)(b + oRays); pb.hit = (float4*)(b + oHit); pb.mult = (float4*)(b + oMult); pb.cnst = (float4*)(b + oCnst);
+    pb.pendL = (float4*)(b + oPend); pb.hitMul = (float4*)(b + oHm); pb.vP = (float4*)(b + oVP); pb.vN = (float4*)(b + oVN);
+    pb.vTex = (float4*)(b + oVT); pb.contrib = (float4*)(b + oContrib); pb.occ = b + oOcc; pb.ksStack = (float4*)(b + oKs);
+    pb.pixel = (int*)(b + oPix); pb.qExt[0] = (int*)(b + oQ0); pb.qExt[1] = (int*)(b + oQ1); pb.qAct = (int*)(b + oQA);
+    pb.shRays = (float4*)(b + oSh); pb.shTarget = (int*)(b + oShT); pb.counters = (unsigned*)(b + oCnt);
+    pb.visitCounters = c->dTotals + 2;
+    return MIPT_OK;
+}
+
+int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_params* rp, float* accum_dev, float* rgb_dev) {
+    if (!c || !cam || !rp || !rgb_dev) return fail(MIPT_ERR_INVALID, "mipt_render_device: null argument");
+    if (rp->mode < MIPT_MODE_PRIMARY || rp->mode > MIPT_MODE_PATH) return fail(MIPT_ERR_INVALID, "unknown render mode");
+    if (rp->mode == MIPT_MODE_PATH && (!accum_dev || rp->spp <= 0 || rp->sample_offset < 0))
+        return fail(MIPT_ERR_INVALID, "path mode needs accum_dev, spp > 0, sample_offset >= 0");
+    const int partCount = rp->part_count > 0 ? rp->part_count : 1;
+    if (rp->part_index < 0 || rp->part_index >= partCount) return fail(MIPT_ERR_INVALID, "part_index out of range");
+    const int tileW = rp->tile_w > 0 ? rp->tile_w : 64, tileH = rp->tile_h > 0 ? rp->tile_h : 8;
+    if ((tileW & 7) || (tileH & 7)) return fail(MIPT_ERR_INVALID, "tile_w and tile_h must be multiples of 8");
+    CameraDev cd;
+    int rc = make_camera(cam, cd);
+    if (rc != MIPT_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+
+    // owned tiles: diagonal interleave over the parts
+    const int tilesX = (cam->width + tileW - 1) / tileW, tilesY = (cam->height + tileH - 1) / tileH;
+    const std::vector<int> key = {cam->width, cam->height, tileW, tileH, rp->part_index, partCount};
+    if (key != c->tileKey) {
+        std::vector<int> tiles;
+        for (int ty = 0; ty < tilesY; ty++)
+            for (int tx = 0; tx < tilesX; tx++)
+                if ((tx + 3 * ty) % partCount == rp->part_index) tiles.push_back(ty * tilesX + tx);
+        if ((rc = c->tileMem.ensure(tiles.size() * sizeof(int) + 4)) != MIPT_OK) return rc;
+        if (!tiles.empty()) HIP_TRY(hipMemcpy(c->tileMem.p, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
+        c->tileKey = key;
+        c->nOwnedTiles = (int)tiles.size();
+    }
+    if (c->nOwnedTiles == 0) return MIPT_OK;
+    const size_t cap = (size_t)c->nOwnedTiles * tileW * tileH;
+    if (cap > ((size_t)1 << 28)) return fail(MIPT_ERR_LIMIT, "more than 2^28 pixels in one partition");
+    if ((rc = ensure_path_buffers(c, cap)) != MIPT_OK) return rc;
+    const PathBuffers& pb = c->pb;
+    const int nl = pb.nLights;
+
+    FrameParams fp{};
+    fp.mode = rp->mode;
+    fp.width = cam->width; fp.height = cam->height;
+    fp.tileW = tileW; fp.tileH = tileH; fp.tilesX = tilesX; fp.nOwnedTiles = c->nOwnedTiles;
+    fp.tileList = (const int*)c->tileMem.p;
+    fp.accum = accum_dev; fp.rgb = rgb_dev;
+    fp.seedHash = pcg_hash_host(rp->seed);
+    const bool unbounded = rp->mode == MIPT_MODE_PATH && rp->max_bounces < 0;
+    int lastIter;
+    if (rp->mode == MIPT_MODE_PATH) {
+        fp.maxBounces = (unbounded || rp->max_bounces > kMaxIter - 2) ? kMaxIter - 2 : rp->max_bounces;
+        lastIter = fp.maxBounces;
+    } else {
+        fp.maxBounces = -1;
+        lastIter = rp->mode == MIPT_MODE_DIRECT ? 6 : 0;  // shade(): level > 5 ends every chain
+    }
+    fp.lastIter = lastIter;
+    const int nSamples = rp->mode == MIPT_MODE_PATH ? rp->spp : 1;
+    for (int sm = 0; sm < nSamples; sm++) {
+        fp.sample = (unsigned)(rp->sample_offset + sm);
+        fp.sampleCount = fp.sample + 1u;  // sampleCount++ before the loop, C:2232
+        HIP_TRY(hipMemsetAsync(pb.counters, 0, (size_t)kMaxIter * 4 * 4, c->stream));
+        {
+            Timer tm(c, 2);
+            count_launch(c, 2);
+            launch_generate(c->stream, cd, fp, pb);
+        }
+        int itDone = 0;
+        for (int it = 0; it <= lastIter; it++) {
+            trace_closest(c, pb.rays, pb.qExt[it & 1], &pb.counters[it * 4 + 0], cap, pb.hit);
+            {
+                Timer tm(c, 2);
+                count_launch(c, 2);
+                launch_shade_a(c->stream, c->ds, fp, pb, it);
+            }
+            if (rp->mode != MIPT_MODE_PRIMARY) {
+                trace_occluded(c, pb.shRays, pb.shTarget, &pb.counters[it * 4 + 2], cap * nl, pb.occ);
+                Timer tm(c, 2);
+                count_launch(c, 2);
+                launch_shade_b(c->stream, c->ds, fp, pb, it);
+            }
+            itDone = it + 1;
+            if (unbounded && it >= 8 && (it & 3) == 0 && it < lastIter) {
+                unsigned next = 0;  // the reference has no bounce cap: stop when no path is left
+                HIP_TRY(hipMemcpyAsync(&next, &pb.counters[(it + 1) * 4], 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (next == 0) break;
+            }
+        }
+        launch_fold_counters(c->stream, pb.counters, itDone, c->dTotals);
+        c->acc.launches_other++;
+    }
+    HIP_TRY(hipGetLastError());
+    return MIPT_OK;
+}
+
+int mipt_render(mipt_ctx* c, const mipt_camera* cam, const mipt_render_params* rp, float* rgb_host) {
+    if (!c || !cam || !rp || !rgb_host) return fail(MIPT_ERR_INVALID, "mipt_render: null argument");
+    if (cam->width <= 0 || cam->height <= 0) return fail(MIPT_ERR_INVALID, "camera: bad resolution");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)3 * cam->width * cam->height * sizeof(float);
+    int rc = c->frameMem.ensure(2 * align256(bytes));
+    if (rc != MIPT_OK) return rc;
+    float* accum = (float*)c->frameMem.p;
+    float* rgb = (float*)((unsigned char*)c->frameMem.p + align256(bytes));
+    HIP_TRY(hipMemsetAsync(c->frameMem.p, 0, 2 * align256(bytes), c->stream));
+    rc = mipt_render_device(c, cam, rp, accum, rgb);
+    if (rc != MIPT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(rgb_host, rgb, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return MIPT_OK;
+}
+
+}  // extern "C"

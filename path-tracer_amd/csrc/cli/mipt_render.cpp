@@ -1,0 +1,103 @@
+// mipt_render -- headless renderer: what main.cpp + CS488Window::start
+// (reference cpu/src/main.cpp:37-103, cs488.h:2598-2651) do, minus the
+// OpenGL window: load .obj/.mtl (+ environment), build the SAH-BVH on the
+// host, upload the arena, render on the GPU, write the image.
+//
+//   mipt_render --scene cornellbox.obj [--env probe.hdr] [--width 512 --height 384]
+//               [--mode primary|direct|path] [--spp 16] [--bounces 4] [--seed 1]
+//               [--eye x y z] [--lookat x y z] [--light x y z w] [--device 0]
+//               [--out image.png] [--out-hdr image.hdr] [--out-pfm image.pfm]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/mipt.h"
+
+static void die(const char* what) {
+    fprintf(stderr, "mipt_render: %s: %s\n", what, mipt_last_error());
+    exit(1);
+}
+
+int main(int argc, char** argv) {
+    std::string scenePath, envPath, outPng, outHdr, outPfm;
+    mipt_camera cam{};
+    cam.width = 512; cam.height = 384;  // globalWidth / globalHeight, cs488.h:45-46
+    cam.eye[2] = 1.5f;                  // cs488.h:81-83
+    cam.up[1] = 1.0f;
+    cam.fov_deg = 45.0f; cam.film_size = 0.032f;
+    mipt_render_params rp{};
+    rp.mode = MIPT_MODE_DIRECT;  // the reference's default frame is Raytrace(), cs488.h:2620
+    rp.spp = 1; rp.max_bounces = 4; rp.seed = 1; rp.part_count = 1;
+    mipt_light light{{3.0f, 3.0f, 3.0f}, {1000.0f, 1000.0f, 1000.0f}};  // main.cpp:26-27
+    int device = 0;
+    for (int i = 1; i < argc; i++) {
+        auto need = [&](int k) { if (i + k >= argc) { fprintf(stderr, "missing value after %s\n", argv[i]); exit(2); } };
+        std::string a = argv[i];
+        if (a == "--scene") { need(1); scenePath = argv[++i]; }
+        else if (a == "--env") { need(1); envPath = argv[++i]; }
+        else if (a == "--width") { need(1); cam.width = atoi(argv[++i]); }
+        else if (a == "--height") { need(1); cam.height = atoi(argv[++i]); }
+        else if (a == "--spp") { need(1); rp.spp = atoi(argv[++i]); }
+        else if (a == "--bounces") { need(1); rp.max_bounces = atoi(argv[++i]); }
+        else if (a == "--seed") { need(1); rp.seed = (uint32_t)strtoul(argv[++i], nullptr, 10); }
+        else if (a == "--device") { need(1); device = atoi(argv[++i]); }
+        else if (a == "--out") { need(1); outPng = argv[++i]; }
+        else if (a == "--out-hdr") { need(1); outHdr = argv[++i]; }
+        else if (a == "--out-pfm") { need(1); outPfm = argv[++i]; }
+        else if (a == "--mode") {
+            need(1);
+            std::string m = argv[++i];
+            rp.mode = m == "primary" ? MIPT_MODE_PRIMARY : m == "path" ? MIPT_MODE_PATH : MIPT_MODE_DIRECT;
+        } else if (a == "--eye") { need(3); for (int k = 0; k < 3; k++) cam.eye[k] = (float)atof(argv[++i]); }
+        else if (a == "--lookat") { need(3); for (int k = 0; k < 3; k++) cam.lookat[k] = (float)atof(argv[++i]); }
+        else if (a == "--light") {
+            need(4);
+            for (int k = 0; k < 3; k++) light.position[k] = (float)atof(argv[++i]);
+            const float w = (float)atof(argv[++i]);
+            light.wattage[0] = light.wattage[1] = light.wattage[2] = w;
+        } else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    mipt_mesh* mesh = nullptr;
+    if (scenePath.empty() || mipt_mesh_load_obj(scenePath.c_str(), &mesh) != MIPT_OK) {
+        // main.cpp:40-44: fall back to the single triangle when the .obj does not load
+        fprintf(stderr, "Invalid .obj file (%s).\nMaking a single triangle instead.\n", mipt_last_error());
+        if (mipt_mesh_create_single_triangle(&mesh) != MIPT_OK) die("single triangle");
+    }
+    printf("Loaded \"%s\" with %d triangles.\n", scenePath.c_str(), mipt_mesh_num_triangles(mesh));
+    mipt_image* env = nullptr;
+    if (!envPath.empty() && mipt_image_load(envPath.c_str(), &env) != MIPT_OK) die("environment");
+    auto t0 = std::chrono::high_resolution_clock::now();
+    mipt_bvh* bvh = nullptr;
+    if (mipt_bvh_build(mesh, &bvh) != MIPT_OK) die("BVH build");
+    auto t1 = std::chrono::high_resolution_clock::now();
+    printf("Built BVH: %d nodes, %d leaves, depth %d (%.1f ms)\n", mipt_bvh_num_nodes(bvh), mipt_bvh_num_leaves(bvh),
+           mipt_bvh_depth(bvh), std::chrono::duration<double, std::milli>(t1 - t0).count());
+    mipt_scene_desc desc;
+    if (mipt_scene_desc_fill(mesh, bvh, env, &light, 1, &desc) != MIPT_OK) die("scene description");
+    mipt_scene* scene = nullptr;
+    if (mipt_scene_create(&desc, &scene) != MIPT_OK) die("scene");
+    mipt_ctx* ctx = nullptr;
+    if (mipt_context_create(scene, device, nullptr, &ctx) != MIPT_OK) die("context");
+    printf("Arena: %zu bytes on device %d\n", mipt_context_arena_bytes(ctx), device);
+    std::vector<float> rgb((size_t)3 * cam.width * cam.height);
+    auto t2 = std::chrono::high_resolution_clock::now();
+    if (mipt_render(ctx, &cam, &rp, rgb.data()) != MIPT_OK) die("render");
+    auto t3 = std::chrono::high_resolution_clock::now();
+    mipt_stats st;
+    mipt_context_get_stats(ctx, &st);
+    const double ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    printf("Frame duration %.2f ms, %llu rays (%.1f Mrays/s)\n", ms,
+           (unsigned long long)(st.rays_closest + st.rays_occluded), (st.rays_closest + st.rays_occluded) / ms * 1e-3);
+    if (!outPng.empty() && mipt_image_save_png(outPng.c_str(), cam.width, cam.height, rgb.data()) != MIPT_OK) die("save png");
+    if (!outHdr.empty() && mipt_image_save_hdr(outHdr.c_str(), cam.width, cam.height, rgb.data()) != MIPT_OK) die("save hdr");
+    if (!outPfm.empty() && mipt_image_save_pfm(outPfm.c_str(), cam.width, cam.height, rgb.data()) != MIPT_OK) die("save pfm");
+    mipt_context_destroy(ctx);
+    mipt_scene_destroy(scene);
+    mipt_bvh_destroy(bvh);
+    if (env) mipt_image_destroy(env);
+    mipt_mesh_destroy(mesh);
+    return 0;
+}

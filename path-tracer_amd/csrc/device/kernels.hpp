@@ -1,0 +1,69 @@
+// kernels.hpp -- host-callable launchers of the HIP kernels and the buffers
+// the wavefront integrator works on.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../../include/mipt.h"
+#include "device_scene.hpp"
+
+namespace ptd {
+
+struct CameraDev;
+
+constexpr unsigned kMaxGrid = 8192;  // blocks; larger queues are grid-strided
+constexpr int kMaxLights = 16;
+constexpr int kMaxIter = 66;         // bounce iterations a frame can enqueue (counter slots)
+
+// Per-path state of the wavefront integrator, SoA of float4 (16-B lane loads).
+// Index p = slot of the path inside this context's pixel partition.
+struct PathBuffers {
+    size_t capacity;      // paths
+    int nLights;
+    float4* rays;         // [2p] = {o.xyz, tmin}, [2p+1] = {d.xyz, tmax}: extension ray of the path
+    float4* hit;          // {bits(tri), t, beta, gamma}
+    float4* mult;         // {multTerm.xyz, currEta}
+    float4* cnst;         // {constTerm.xyz, bits(flags)}    flags bit0: currDir = -ray.d, bits 8..: metal depth (direct)
+    float4* pendL;        // {L.xyz, bits(missMode)}         what the vertex that shot the ray still owes
+    float4* hitMul;       // {multiplier applied to multTerm on a hit, bits(rng dimension)}
+    float4* vP;           // {P.xyz, bits(material)}          vertex cache shadeA -> shadeB
+    float4* vN;           // {N.xyz, 0}
+    float4* vTex;         // {texture.xyz, 0}   (direct mode: brdf)
+    float4* contrib;      // [p*nLights+i] {unshadowed contribution of light i (direct: irradiance), bits(state)}
+    unsigned char* occ;   // [p*nLights+i] 1 = occluded
+    float4* ksStack;      // [p*6+k] metal Ks chain (direct mode)
+    int* pixel;           // pixel index of the path, -1 = outside the image
+    int* qExt[2];         // ping-pong queues of path slots to extend
+    int* qAct;            // Lambertian vertices waiting for their shadow rays
+    float4* shRays;       // shadow-ray queue, 2 float4 per ray
+    int* shTarget;        // occ index each shadow ray reports to
+    unsigned* counters;   // [kMaxIter][4]: nExt, nAct, nShadow, pad
+    unsigned long long* visitCounters;  // [2] closest: node visits, tri tests; [2] occluded
+};
+
+struct FrameParams {
+    int mode, level, maxBounces, lastIter;
+    unsigned seedHash, sample, sampleCount;
+    int width, height;
+    int tileW, tileH, tilesX, nOwnedTiles;
+    const int* tileList;  // owned tile ids
+    float* accum;
+    float* rgb;
+};
+
+void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index,
+                          const unsigned* countPtr, size_t nMax, float4* hits, unsigned long long* counters);
+void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target,
+                           const unsigned* countPtr, size_t nMax, unsigned char* occ, unsigned long long* counters);
+void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays);
+void launch_resolve_hits(hipStream_t st, const DevScene& s, const float4* rays, const float4* hits, size_t n,
+                         float* out);
+void launch_background(hipStream_t st, const DevScene& s, const float* dir, size_t n, float* rgb);
+
+// integrator (kernels_integrate.hip)
+void launch_generate(hipStream_t st, const CameraDev& cam, const FrameParams& fp, const PathBuffers& pb);
+void launch_shade_a(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter);
+void launch_shade_b(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter);
+// totals[0] += sum of extension-queue lengths, totals[1] += sum of shadow-queue lengths over iterations [0, nIter)
+void launch_fold_counters(hipStream_t st, const unsigned* counters, int nIter, unsigned long long* totals);
+
+}  // namespace ptd

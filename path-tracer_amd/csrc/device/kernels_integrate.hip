@@ -1,0 +1,447 @@
+// kernels_integrate.hip -- wavefront integrator around the traversal kernels.
+//
+// One bounce iteration `it` (= the reference's currlevel / level) is
+//     extend(it) -> shade_a(it) -> occluded(it) -> shade_b(it)
+// shade_a resolves the extension ray's result (miss: the path ends with what
+// the previous vertex left pending; hit: pending terms are applied), then
+// handles the new vertex: metal / glass shoot the next extension ray at once,
+// a Lambertian vertex emits its shadow rays and waits in qAct; shade_b
+// finishes Lambertian vertices (light sum, Russian roulette, cosine sample).
+// Queues are compacted with wavefront ballots: one atomic per 64 lanes.
+// Queue lengths stay in device memory, so a frame is enqueued without syncs.
+//
+// Semantics restated from the reference (cs488.h): Scene::Pathtrace :2230-2261,
+// shade_pathtrace :2267-2397, Scene::Raytrace :2200-2229, shade :2402-2496.
+// Quirks are kept (see DESIGN.md "integrator quirks").
+#include "kernels.hpp"
+#include "shading.hpp"
+
+namespace ptd {
+
+enum : int { FLAG_NEGD = 1 };  // currDir / viewDir of the vertex is -ray.d
+enum : int { MISS_LAMBERT = 0, MISS_SPECULAR = 1 };
+constexpr float kFltMax = 3.402823466e+38f;
+
+// slot for each lane whose pred is set; one atomicAdd per wavefront
+__device__ __forceinline__ unsigned wave_append(unsigned* counter, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ vec3 xyz(const float4 v) { return vec3{v.x, v.y, v.z}; }
+__device__ __forceinline__ float4 pack(const vec3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+
+// AccumulationBuffer += result; FrameBuffer = Accum / sampleCount  (C:2240-2241)
+__device__ __forceinline__ void finish_path(const FrameParams& fp, int pix, const vec3 result) {
+    float* a = fp.accum + (size_t)3 * pix;
+    float* q = fp.rgb + (size_t)3 * pix;
+    const float ax = a[0] + result.x, ay = a[1] + result.y, az = a[2] + result.z;
+    a[0] = ax; a[1] = ay; a[2] = az;
+    const float sc = (float)fp.sampleCount;
+    q[0] = ax / sc; q[1] = ay / sc; q[2] = az / sc;
+}
+__device__ __forceinline__ void write_pixel(const FrameParams& fp, int pix, const vec3 v) {
+    float* q = fp.rgb + (size_t)3 * pix;
+    q[0] = v.x; q[1] = v.y; q[2] = v.z;
+}
+
+// ---- generate: eye rays for this context's tiles (C:2183-2197) ----
+__global__ __launch_bounds__(kBlock) void k_generate(CameraDev cam, FrameParams fp, PathBuffers pb) {
+    const unsigned tilePix = (unsigned)(fp.tileW * fp.tileH);
+    const unsigned n = (unsigned)fp.nOwnedTiles * tilePix;
+    const unsigned nRound = (n + 63u) & ~63u;
+    for (unsigned p = blockIdx.x * kBlock + threadIdx.x; p < nRound; p += gridDim.x * kBlock) {
+        bool valid = p < n;
+        int pix = -1;
+        if (valid) {
+            const unsigned k = p / tilePix, r = p % tilePix;
+            const unsigned blk = r >> 6, lane = r & 63u;  // 8x8 pixel block per wavefront
+            const unsigned bpr = (unsigned)fp.tileW >> 3;
+            const int lx = (int)((blk % bpr) * 8u + (lane & 7u));
+            const int ly = (int)((blk / bpr) * 8u + (lane >> 3));
+            const int t = fp.tileList[k];
+            const int x = (t % fp.tilesX) * fp.tileW + lx;
+            const int y = (t / fp.tilesX) * fp.tileH + ly;
+            valid = (x < fp.width) && (y < fp.height);
+            if (valid) {
+                pix = y * fp.width + x;
+                vec3 o, d;
+                eye_ray(cam, x, y, o, d);
+                pb.rays[2 * (size_t)p] = pack(o, 0.0f);
+                pb.rays[2 * (size_t)p + 1] = pack(d, kFltMax);
+            }
+            pb.pixel[p] = pix;
+        }
+        const unsigned slot = wave_append(&pb.counters[0], valid);
+        if (valid) pb.qExt[0][slot] = (int)p;
+    }
+}
+
+// emit the next extension ray of path p
+__device__ __forceinline__ void emit_extension(const PathBuffers& pb, unsigned p, const vec3 P, float tmin, const vec3 dir) {
+    pb.rays[2 * (size_t)p] = pack(P, tmin);
+    pb.rays[2 * (size_t)p + 1] = pack(dir, kFltMax);
+}
+
+// ---- path mode ----
+__global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams fp, PathBuffers pb, int it) {
+    const unsigned n = pb.counters[it * 4 + 0];
+    const unsigned nRound = (n + 63u) & ~63u;
+    const int* q = pb.qExt[it & 1];
+    int* qNext = pb.qExt[(it + 1) & 1];
+    unsigned* cNext = &pb.counters[(it + 1) * 4 + 0];
+    unsigned* cAct = &pb.counters[it * 4 + 1];
+    unsigned* cSh = &pb.counters[it * 4 + 2];
+    const int nl = pb.nLights;
+    const bool capped = (fp.maxBounces >= 0) && (it >= fp.maxBounces);
+
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nRound; i += gridDim.x * kBlock) {
+        const bool valid = i < n;
+        bool toExt = false, toAct = false;
+        unsigned p = 0;
+        int pix = 0;
+        vec3 P{0, 0, 0}, N{0, 0, 0};
+        if (valid) {
+            p = (unsigned)q[i];
+            pix = pb.pixel[p];
+            const float4 r1 = pb.rays[2 * (size_t)p + 1];
+            const vec3 d = xyz(r1);
+            const float4 h = pb.hit[p];
+            const int tri = f2i(h.x);
+            vec3 mult{1.0f, 1.0f, 1.0f}, cnst{0.0f, 0.0f, 0.0f};
+            float eta = 1.0f;
+            int flags = FLAG_NEGD;
+            bool alive = true;
+            if (it == 0) {
+                if (tri < 0) {  // C:2244: miss pixels show the background, unaccumulated
+                    write_pixel(fp, pix, get_background(s, -d));
+                    alive = false;
+                } else {
+                    pb.hitMul[p] = make_float4(1.0f, 1.0f, 1.0f, i2f(0));  // rng dimension 0
+                }
+            } else {
+                const float4 m4 = pb.mult[p], c4 = pb.cnst[p], l4 = pb.pendL[p];
+                mult = xyz(m4); eta = m4.w; cnst = xyz(c4); flags = f2i(c4.w);
+                const vec3 L = xyz(l4);
+                const int missMode = f2i(l4.w);
+                if (tri < 0) {
+                    const vec3 result = (missMode == MISS_LAMBERT) ? cnst + mult * L : cnst + mult * get_background(s, d);
+                    finish_path(fp, pix, result);
+                    alive = false;
+                } else {
+                    if (missMode == MISS_LAMBERT) cnst = cnst + L * mult;  // C:2322
+                    mult = mult * xyz(pb.hitMul[p]);                       // C:2323 / C:2348
+                }
+            }
+            if (alive) {
+                const HitInfo hi = reconstruct_hit(s, tri, h.y, h.z, h.w, d);
+                const MaterialDev m = load_material(s, hi.material);
+                const vec3 currDir = (flags & FLAG_NEGD) ? -d : d;
+                P = hi.P; N = hi.N;
+                if (m.type == MIPT_MAT_LAMBERTIAN) {
+                    vec3 texture{1.0f, 1.0f, 1.0f};
+                    if (m.texOfs >= 0) texture = texture * fetch_texture(s, m, hi.T);
+                    const vec3 brdf = m.Kd / kPI;
+                    for (int k = 0; k < nl; k++) {  // C:2287-2310
+                        const float4 lp = s.lights[2 * k], lw = s.lights[2 * k + 1];
+                        vec3 l = xyz(lp) - P;
+                        const float falloff = pt::length2(l);
+                        l = l / sqrtf(falloff);
+                        const float ndl = pt::dot(N, l);
+                        const vec3 irradiance = light_factor(ndl, falloff) * xyz(lw);
+                        const bool need = ndl > 0.0f;
+                        pb.contrib[(size_t)p * nl + k] = pack((irradiance * texture) * brdf, i2f(need ? 1 : 0));
+                        pb.occ[(size_t)p * nl + k] = 0;
+                        // shadow ray P -> light, (0, dist), C:2303 / C:2428; the lanes here are
+                        // exactly the Lambertian vertices, the ballot sees only them
+                        const unsigned sl = wave_append(cSh, need);
+                        if (need) {
+                            pb.shRays[2 * (size_t)sl] = pack(P, 0.0f);
+                            pb.shRays[2 * (size_t)sl + 1] = pack(pt::normalize(l), sqrtf(falloff));
+                            pb.shTarget[sl] = (int)((size_t)p * nl + k);
+                        }
+                    }
+                    pb.vP[p] = pack(P, i2f(hi.material));
+                    pb.vN[p] = pack(N, 0.0f);
+                    pb.vTex[p] = pack(texture, 0.0f);
+                    pb.mult[p] = pack(mult, eta);
+                    pb.cnst[p] = pack(cnst, i2f(flags));
+                    toAct = true;
+                } else if (m.type == MIPT_MAT_METAL) {
+                    if (capped) {
+                        finish_path(fp, pix, cnst);
+                    } else {
+                        const vec3 smp = mirror(-currDir, N);  // C:496
+                        emit_extension(pb, p, P, 0.001f, smp);
+                        pb.pendL[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(MISS_SPECULAR));
+                        const float4 hm = pb.hitMul[p];
+                        pb.hitMul[p] = pack(m.Ks, hm.w);
+                        pb.mult[p] = pack(mult, eta);
+                        pb.cnst[p] = pack(cnst, i2f(0));
+                        toExt = true;
+                    }
+                } else if (m.type == MIPT_MAT_GLASS) {
+                    if (capped) {
+                        finish_path(fp, pix, cnst);
+                    } else {
+                        const float eta2 = (m.eta == eta) ? 1.0f : m.eta;  // C:2359
+                        const vec3 w = -currDir;
+                        const float ratio = eta / eta2;
+                        const float inside = snell_inside(ratio, pt::dot(w, N));
+                        const float4 hm = pb.hitMul[p];
+                        pb.hitMul[p] = make_float4(1.0f, 1.0f, 1.0f, hm.w);
+                        pb.pendL[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(MISS_SPECULAR));
+                        if (inside >= 0.0f) {  // C:2366-2377; the ray direction is -refracted
+                            emit_extension(pb, p, P, 0.01f, refract_dir(w, N, ratio, inside));
+                            pb.mult[p] = pack(mult, eta2);
+                            pb.cnst[p] = pack(cnst, i2f(FLAG_NEGD));
+                        } else {  // total internal reflection, C:2378-2389
+                            emit_extension(pb, p, P, 0.0f, mirror(w, N));
+                            pb.mult[p] = pack(mult, eta);
+                            pb.cnst[p] = pack(cnst, i2f(0));
+                        }
+                        toExt = true;
+                    }
+                } else {
+                    finish_path(fp, pix, vec3{0.0f, 0.0f, 0.0f});  // C:2391-2394, constTerm is dropped
+                }
+            }
+        }
+        const unsigned sExt = wave_append(cNext, toExt);
+        if (toExt) qNext[sExt] = (int)p;
+        const unsigned sAct = wave_append(cAct, toAct);
+        if (toAct) pb.qAct[sAct] = (int)p;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade_b_path(DevScene s, FrameParams fp, PathBuffers pb, int it) {
+    const unsigned n = pb.counters[it * 4 + 1];
+    const unsigned nRound = (n + 63u) & ~63u;
+    int* qNext = pb.qExt[(it + 1) & 1];
+    unsigned* cNext = &pb.counters[(it + 1) * 4 + 0];
+    const int nl = pb.nLights;
+    const bool capped = (fp.maxBounces >= 0) && (it >= fp.maxBounces);
+
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nRound; i += gridDim.x * kBlock) {
+        const bool valid = i < n;
+        bool toExt = false;
+        unsigned p = 0;
+        if (valid) {
+            p = (unsigned)pb.qAct[i];
+            const int pix = pb.pixel[p];
+            const float4 m4 = pb.mult[p], c4 = pb.cnst[p];
+            const vec3 mult = xyz(m4), cnst = xyz(c4);
+            vec3 L{0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < nl; k++) {  // C:2303-2309
+                const float4 c = pb.contrib[(size_t)p * nl + k];
+                if (f2i(c.w) && pb.occ[(size_t)p * nl + k]) continue;
+                L = L + xyz(c);
+            }
+            const float4 hm = pb.hitMul[p];
+            unsigned dim = (unsigned)f2i(hm.w);
+            bool done = capped;
+            if (!done && it > 5) {  // C:2311-2314, no weight compensation
+                if (counter_rand(fp.seedHash, (unsigned)pix, fp.sample, dim++) < .25f) done = true;
+            }
+            if (done) {
+                finish_path(fp, pix, cnst + mult * L);
+            } else {
+                const float4 p4 = pb.vP[p];
+                const vec3 P = xyz(p4), N = xyz(pb.vN[p]), texture = xyz(pb.vTex[p]);
+                const MaterialDev m = load_material(s, f2i(p4.w));
+                const float u1 = counter_rand(fp.seedHash, (unsigned)pix, fp.sample, dim++);
+                const float u2 = counter_rand(fp.seedHash, (unsigned)pix, fp.sample, dim++);
+                const vec3 smp = sample_lambert(N, u1, u2);
+                const vec3 sample_brdf = m.Kd / kPI;
+                const float pdf = 1.0f / kPI;
+                emit_extension(pb, p, P, 0.001f, smp);
+                pb.pendL[p] = pack(L, i2f(MISS_LAMBERT));
+                pb.hitMul[p] = pack((texture * sample_brdf) / pdf, i2f((int)dim));
+                pb.cnst[p] = pack(cnst, i2f(0));
+                toExt = true;
+            }
+        }
+        const unsigned sExt = wave_append(cNext, toExt);
+        if (toExt) qNext[sExt] = (int)p;
+    }
+}
+
+// ---- direct mode (shade) ----
+__device__ __forceinline__ vec3 unwind_metal(const PathBuffers& pb, unsigned p, int depth, vec3 v) {
+    for (int k = depth - 1; k >= 0; --k) v = xyz(pb.ksStack[(size_t)p * 6 + k]) * v;  // C:2463
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade_a_direct(DevScene s, FrameParams fp, PathBuffers pb, int it) {
+    const unsigned n = pb.counters[it * 4 + 0];
+    const unsigned nRound = (n + 63u) & ~63u;
+    const int* q = pb.qExt[it & 1];
+    int* qNext = pb.qExt[(it + 1) & 1];
+    unsigned* cNext = &pb.counters[(it + 1) * 4 + 0];
+    unsigned* cAct = &pb.counters[it * 4 + 1];
+    unsigned* cSh = &pb.counters[it * 4 + 2];
+    const int nl = pb.nLights;
+    const int level = it;
+
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nRound; i += gridDim.x * kBlock) {
+        const bool valid = i < n;
+        bool toExt = false, toAct = false;
+        unsigned p = 0;
+        vec3 P{0, 0, 0};
+        if (valid) {
+            p = (unsigned)q[i];
+            const int pix = pb.pixel[p];
+            const vec3 d = xyz(pb.rays[2 * (size_t)p + 1]);
+            const float4 h = pb.hit[p];
+            const int tri = f2i(h.x);
+            float eta = 1.0f;
+            int flags = FLAG_NEGD, depth = 0;
+            if (it > 0) {
+                const float4 c4 = pb.cnst[p];
+                eta = pb.mult[p].w;
+                flags = f2i(c4.w) & 0xff;
+                depth = f2i(c4.w) >> 8;
+            }
+            if (tri < 0) {  // C:2212, C:2462, C:2478, C:2488: always the background at -d
+                write_pixel(fp, pix, unwind_metal(pb, p, depth, get_background(s, -d)));
+            } else if (fp.mode == 0) {  // primary only: (t, triangle id, material)
+                const HitInfo hi = reconstruct_hit(s, tri, h.y, h.z, h.w, d);
+                write_pixel(fp, pix, vec3{h.y, (float)tri, (float)hi.material});
+            } else {
+                const HitInfo hi = reconstruct_hit(s, tri, h.y, h.z, h.w, d);
+                const MaterialDev m = load_material(s, hi.material);
+                const vec3 viewDir = (flags & FLAG_NEGD) ? -d : d;
+                const vec3 N = hi.N;
+                P = hi.P;
+                if (m.type == MIPT_MAT_LAMBERTIAN) {
+                    vec3 brdf = m.Kd / kPI;
+                    if (m.texOfs >= 0) brdf = brdf * fetch_texture(s, m, hi.T);
+                    for (int k = 0; k < nl; k++) {  // C:2409-2435
+                        const float4 lp = s.lights[2 * k], lw = s.lights[2 * k + 1];
+                        vec3 l = xyz(lp) - P;
+                        const float falloff = pt::length2(l);
+                        l = l / sqrtf(falloff);
+                        const float ndl = pt::dot(N, l);
+                        const vec3 irradiance = light_factor(ndl, falloff) * xyz(lw);
+                        const bool need = ndl > 0.0f;
+                        pb.contrib[(size_t)p * nl + k] = pack(irradiance, i2f(need ? 1 : 0));
+                        pb.occ[(size_t)p * nl + k] = 0;
+                        // shadow ray P -> light, (0, dist), C:2303 / C:2428; the lanes here are
+                        // exactly the Lambertian vertices, the ballot sees only them
+                        const unsigned sl = wave_append(cSh, need);
+                        if (need) {
+                            pb.shRays[2 * (size_t)sl] = pack(P, 0.0f);
+                            pb.shRays[2 * (size_t)sl + 1] = pack(pt::normalize(l), sqrtf(falloff));
+                            pb.shTarget[sl] = (int)((size_t)p * nl + k);
+                        }
+                    }
+                    pb.vTex[p] = pack(brdf, 0.0f);
+                    pb.cnst[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(flags | (depth << 8)));
+                    toAct = true;
+                } else if (m.type == MIPT_MAT_METAL) {
+                    if (level > 5) {
+                        write_pixel(fp, pix, unwind_metal(pb, p, depth, vec3{(float).1, (float).1, (float).1}));
+                    } else {
+                        const vec3 reflected = mirror(-viewDir, N);  // C:2459
+                        emit_extension(pb, p, P, 0.001f, reflected);
+                        pb.ksStack[(size_t)p * 6 + depth] = pack(m.Ks, 0.0f);
+                        pb.cnst[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(0 | ((depth + 1) << 8)));
+                        pb.mult[p] = make_float4(1.0f, 1.0f, 1.0f, eta);
+                        toExt = true;
+                    }
+                } else if (m.type == MIPT_MAT_GLASS) {
+                    if (level > 5) {
+                        write_pixel(fp, pix, unwind_metal(pb, p, depth, vec3{0.0f, 0.0f, 0.0f}));
+                    } else {
+                        const float eta2 = (m.eta == eta) ? 1.0f : m.eta;
+                        const vec3 w = -viewDir;
+                        const float ratio = eta / eta2;
+                        const float inside = snell_inside(ratio, pt::dot(w, N));
+                        if (inside >= 0.0f) {  // C:2474-2480: next viewDir = -refracted = -ray.d
+                            emit_extension(pb, p, P, 0.0f, refract_dir(w, N, ratio, inside));
+                            pb.cnst[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(FLAG_NEGD | (depth << 8)));
+                            pb.mult[p] = make_float4(1.0f, 1.0f, 1.0f, eta2);
+                        } else {  // C:2481-2490
+                            emit_extension(pb, p, P, 0.0f, mirror(w, N));
+                            pb.cnst[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(0 | (depth << 8)));
+                            pb.mult[p] = make_float4(1.0f, 1.0f, 1.0f, eta);
+                        }
+                        toExt = true;
+                    }
+                } else {
+                    write_pixel(fp, pix, unwind_metal(pb, p, depth, vec3{100.0f, 0.0f, 100.0f}));  // C:2494
+                }
+            }
+        }
+        const unsigned sExt = wave_append(cNext, toExt);
+        if (toExt) qNext[sExt] = (int)p;
+        const unsigned sAct = wave_append(cAct, toAct);
+        if (toAct) pb.qAct[sAct] = (int)p;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade_b_direct(DevScene s, FrameParams fp, PathBuffers pb, int it) {
+    const unsigned n = pb.counters[it * 4 + 1];
+    const int nl = pb.nLights;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const unsigned p = (unsigned)pb.qAct[i];
+        const int pix = pb.pixel[p];
+        const vec3 brdf = xyz(pb.vTex[p]);
+        const int depth = f2i(pb.cnst[p].w) >> 8;
+        vec3 L{0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < nl; k++) {
+            const float4 c = pb.contrib[(size_t)p * nl + k];
+            vec3 irradiance = xyz(c);
+            if (f2i(c.w) && pb.occ[(size_t)p * nl + k]) irradiance = vec3{0.1f, 0.1f, 0.1f} * irradiance;  // C:2428-2431
+            L = L + irradiance * brdf;
+        }
+        write_pixel(fp, pix, unwind_metal(pb, p, depth, L));
+    }
+}
+
+__global__ void k_fold_counters(const unsigned* __restrict__ counters, int nIter, unsigned long long* totals) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long e = 0, sh = 0;
+        for (int it = 0; it < nIter; it++) {
+            e += counters[it * 4 + 0];
+            sh += counters[it * 4 + 2];
+        }
+        totals[0] += e;
+        totals[1] += sh;
+    }
+}
+
+// ---- launchers ----
+static inline unsigned grid_for(size_t n) {
+    size_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return (unsigned)g;
+}
+
+void launch_generate(hipStream_t st, const CameraDev& cam, const FrameParams& fp, const PathBuffers& pb) {
+    const size_t n = (size_t)fp.nOwnedTiles * fp.tileW * fp.tileH;
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(n)), dim3(kBlock), 0, st, cam, fp, pb);
+}
+void launch_shade_a(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter) {
+    const unsigned g = grid_for(pb.capacity);
+    if (fp.mode == 2) hipLaunchKernelGGL(k_shade_a_path, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
+    else hipLaunchKernelGGL(k_shade_a_direct, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
+}
+void launch_shade_b(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter) {
+    const unsigned g = grid_for(pb.capacity);
+    if (fp.mode == 2) hipLaunchKernelGGL(k_shade_b_path, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
+    else hipLaunchKernelGGL(k_shade_b_direct, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
+}
+
+void launch_fold_counters(hipStream_t st, const unsigned* counters, int nIter, unsigned long long* totals) {
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, st, counters, nIter, totals);
+}
+
+}  // namespace ptd

@@ -1,0 +1,127 @@
+"""GPU parity tests proper: the HIP traversal through the C-ABI against the
+CPU oracle (bit-exact: triangle ids, t, barycentrics, HitInfo) on the same
+rays, against the committed golden fixtures, and size-independent properties
+at the BASELINE resolutions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["cornellbox", "cube", "textured", "teapot-glass", "testObj", "bunny"]
+
+_cache = {}
+
+
+def setup_scene(B, sf, name, env=None):
+    key = (name, env is not None)
+    if key not in _cache:
+        arrays = sf.load_scene_arrays(name)
+        scene = sf.product_scene_from_mesh_arrays(*arrays, env=env)
+        ctx = B.Context(scene, device=0)
+        orc = sf.oracle_scene_from_mesh_arrays(*arrays, env=env)
+        _cache[key] = (scene, ctx, orc)
+    return _cache[key]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_primary_hits_bit_exact_vs_oracle_and_golden(B, ob, sf, name):
+    scene, ctx, orc = setup_scene(B, sf, name)
+    g = sf.load_golden(name)
+    w, h = int(g["width"]), int(g["height"])
+    cam = B.default_camera(w, h)
+    o, d = ctx.eye_rays(cam)
+    oo, od = orc.eye_rays(ob.make_camera(w, h))
+    assert np.array_equal(bits(o), bits(oo)) and np.array_equal(bits(d), bits(od)), "eye rays differ bitwise"
+    tri, t, bary, rec = ctx.trace(o, d, want_hitrec=True)
+    otri, ot, obary, orec = orc.intersect(oo, od, want_hitrec=True)
+    assert np.array_equal(tri, otri)
+    assert np.array_equal(bits(t), bits(ot))
+    assert np.array_equal(bits(bary), bits(obary))
+    assert np.array_equal(bits(rec), bits(orec)), "HitInfo (t,P,N,T,material) differs bitwise"
+    hit = tri >= 0
+    assert int(hit.sum()) == int(g["hits"])
+    assert ob.fnv1a32_of_bits(bits(t[hit])) == int(g["fnv_t"])
+    assert ob.fnv1a32_of_bits(bits(tri)) == int(g["fnv_tri"])
+    assert ob.fnv1a32_of_bits(bits(bary[hit]).reshape(-1)) == int(g["fnv_bary"])
+    s = int(g["stride"])
+    assert np.array_equal(tri[::s], g["sub_tri"]) and np.array_equal(bits(t[::s]), bits(g["sub_t"]))
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "bunny", "testObj"])
+def test_secondary_rays_and_windows(B, ob, sf, name):
+    """incoherent rays from surface points, with tMin/tMax windows, plus degenerate directions"""
+    scene, ctx, orc = setup_scene(B, sf, name)
+    rng = np.random.default_rng(7)
+    n = 40000
+    cam = B.default_camera(256, 192)
+    o, d = ctx.eye_rays(cam)
+    tri, t, _ = ctx.trace(o, d)
+    hit = np.flatnonzero(tri >= 0)
+    pick = rng.choice(hit, n)
+    P = (o[pick] + d[pick] * t[pick, None]).astype(np.float32)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True).astype(np.float32)
+    # axis-aligned and zero-component directions: divisions by zero in the slab test
+    dirs[:200] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 200)] * rng.choice([-1.0, 1.0], (200, 1)).astype(np.float32)
+    dirs[200:400, rng.integers(0, 3)] = 0.0
+    for tmin, tmax in ((0.001, B.FLT_MAX), (0.01, 0.5), (0.0, B.FLT_MAX)):
+        a = ctx.trace(P, dirs, tmin, tmax)
+        b = orc.intersect(P, dirs, tmin, tmax)
+        assert np.array_equal(a[0], b[0])
+        assert np.array_equal(bits(a[1]), bits(b[1]))
+        assert np.array_equal(bits(a[2]), bits(b[2]))
+    tmax = rng.uniform(0.05, 3.0, n).astype(np.float32)
+    occ = ctx.occluded(P, dirs, 0.0, tmax)
+    assert np.array_equal(occ, orc.occluded(P, dirs, 0.0, tmax))
+    # any-hit == "closest-hit found something" (Scene::isHit, cs488.h:2056-2068)
+    assert np.array_equal(occ, orc.occluded(P, dirs, 0.0, tmax, variant=ob.BITTRAIL))
+
+
+def test_edge_cases(B, ob, sf):
+    scene, ctx, orc = setup_scene(B, sf, "cornellbox")
+    # empty batch
+    tri, t, bary = ctx.trace(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert tri.size == 0
+    # NaN / inf / zero directions, origins inside and far outside
+    o = np.array([[0, 0, 1.5], [0, 0, 1.5], [0, 0, 1.5], [1e30, 0, 0], [0, 0, 0], [0, 0, 0]], np.float32)
+    d = np.array([[0, 0, 0], [np.nan, 0, -1], [np.inf, 0, -1], [-1, 0, 0], [0, 1, 0], [0, 0, -1]], np.float32)
+    a = ctx.trace(o, d)
+    b = orc.intersect(o, d)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+def test_single_triangle_known_answer(B, ob):
+    """createSingleTriangle (cs488.h:949-970): ray down -z through the centroid hits at t = 1.5"""
+    mesh = B.Mesh.single_triangle()
+    scene = B.Scene(mesh)
+    ctx = B.Context(scene)
+    o = np.array([[0.0, -1.0 / 6.0, 1.5], [2.0, 2.0, 1.5]], np.float32)
+    d = np.array([[0.0, 0.0, -1.0], [0.0, 0.0, -1.0]], np.float32)
+    tri, t, bary, rec = ctx.trace(o, d, want_hitrec=True)
+    assert tri.tolist() == [0, -1]
+    assert t[0] == np.float32(1.5)
+    assert np.allclose(rec[0, 4:7], [0, 0, 1])  # normal +z, facing the ray origin
+
+
+@pytest.mark.parametrize("name,w,h", [("cornellbox", 512, 512), ("bunny", 1024, 1024), ("teapot-glass", 1920, 1080)])
+def test_full_size_properties(B, ob, sf, name, w, h):
+    """BASELINE resolutions: hit ids bit-exact on a row subsample against the oracle; device-side eye rays +
+    device trace agree with the host-pointer entry point; hits lie on their triangles"""
+    scene, ctx, orc = setup_scene(B, sf, name)
+    cam = B.default_camera(w, h)
+    o, d = ctx.eye_rays(cam)
+    tri, t, bary = ctx.trace(o, d)
+    rows = np.arange(0, h, max(1, h // 24))
+    idx = (rows[:, None] * w + np.arange(w)[None, :]).reshape(-1)
+    otri, ot, obary = orc.intersect(o[idx], d[idx])
+    assert np.array_equal(tri[idx], otri) and np.array_equal(bits(t[idx]), bits(ot))
+    # barycentric validity and t window on every hit
+    hit = tri >= 0
+    assert np.all(t[hit] > 1e-5) and np.all(bary[hit] >= 0) and np.all(bary[hit].sum(axis=1) <= 1.0 + 1e-6)
+    # idempotence: tracing the same rays again gives the same bits
+    tri2, t2, _ = ctx.trace(o, d)
+    assert np.array_equal(tri, tri2) and np.array_equal(bits(t), bits(t2))
