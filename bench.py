@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the ray/scene hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json metric: "Mrays/s ... Sponza 1080p path trace; ms/frame
+@1spp", configs[3]): sponza-standin (procedural atrium, 65,536 triangles --
+the real sponza.obj is not in the reference tree), procedural angular-map
+environment (stand-in for uffizi_probe.hdr), 1920x1080, path traced, 4
+bounces, light (0.5,4,1)/1000 W (main.cpp:24).  One step = one frame at 1 spp
+per GPU: with N GPUs a step takes N samples of the frame, image tiles are
+interleaved over the ranks (scene replicated per GPU), every rank renders its
+tiles for those N samples and the tiles are gathered to rank 0 over RCCL.
+Per-GPU work per step is therefore fixed ("weak").  A ray = one closest-hit or
+any-hit traversal (primary, extension and shadow rays each count 1).
+
+The scene arena, accumulation and frame buffers are resident in HBM before the
+timed region.  torch is plumbing only: device buffers, the stream, RCCL.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+W, H, BOUNCES, SEED = 1920, 1080, 4, 1
+TILE_W, TILE_H = 64, 8
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(rays, node_visits, tri_tests):
+    """32 B ray in + 16 B hit out, 32 B per node visit, 36 B per triangle test"""
+    return 48 * rays + 32 * node_visits + 36 * tri_tests
+
+
+def cpu_baseline(arrays, env, lights, eye, lookat):
+    """the oracle (CPU restatement, pinned against the reference's recorded outputs) timed on this host:
+    1 thread, bit-trail traversal (what the reference's Scene instantiates, cs488.h:2008), same scene and
+    settings, on a bounded sample of the frame's rows"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_binding as ob
+    import scene_fixtures as sf
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays, env=env, lights=lights)
+    cam = ob.make_camera(W, H, eye=eye, lookat=lookat)
+    rows, rays, t0 = 0, 0, time.perf_counter()
+    # every 24th row first (a representative cut of the frame), keep adding rows for ~12 s
+    order = [r for phase in range(24) for r in range(phase, H, 24)]
+    rgb = None
+    for r in order:
+        rgb = orc.pathtrace(cam, spp=1, max_bounces=BOUNCES, rng_mode=1, seed=SEED, variant=ob.BITTRAIL, rows=(r, r + 1))
+        rays += orc.last_rays
+        rows += 1
+        if rows >= 45 and time.perf_counter() - t0 > 12.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{rows} of {H} rows (interleaved every 24th) of the same 1920x1080 1-spp 4-bounce frame, "
+                      f"{rays} rays in {dt:.1f} s, bit-trail traversal, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail", type=int, default=1, help="sponza-standin tessellation (1: 65,536 tris, 2: 256,768)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import scene_fixtures as sf
+    B = importlib.import_module("path-tracer_amd").binding
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- scene: host-side load/build, then one arena upload ----
+    arrays = sf.sponza_standin(args.detail)
+    env = sf.procedural_env(1024)
+    scene = sf.product_scene_from_mesh_arrays(*arrays, env=env, lights=sf.SPONZA_LIGHT)
+    stream = torch.cuda.current_stream(dev)
+    ctx = B.Context(scene, device=local_rank, stream=stream.cuda_stream)
+    cam = B.make_camera(W, H, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
+    accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    rgb = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+
+    # pixels this rank owns (same rule as mipt_render_params: (tx + 3*ty) % parts == part), for the gather
+    tiles_x, tiles_y = (W + TILE_W - 1) // TILE_W, (H + TILE_H - 1) // TILE_H
+    ty, tx = np.meshgrid(np.arange(tiles_y), np.arange(tiles_x), indexing="ij")
+    owner_of_tile = (tx + 3 * ty) % world
+    py, px = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    owner = owner_of_tile[py // TILE_H, px // TILE_W]
+    own_idx = [torch.from_numpy(np.flatnonzero(owner.reshape(-1) == r)).to(dev) for r in range(world)]
+    max_own = max(int(i.numel()) for i in own_idx)
+    send = torch.zeros(max_own * 3, dtype=torch.float32, device=dev)
+    recv = [torch.zeros(max_own * 3, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+    rgb3 = rgb.view(-1, 3)
+
+    spp_per_step = world  # one frame-equivalent of paths per GPU per step
+    state = {"sample": 0}
+
+    def step():
+        p = B.RenderParams(B.MODE_PATH, spp_per_step, state["sample"], BOUNCES, SEED, rank, world, TILE_W, TILE_H)
+        ctx.render_device(cam, p, accum.data_ptr(), rgb.data_ptr())
+        state["sample"] += spp_per_step
+        if world > 1:  # tiles -> rank 0 (RCCL gather over xGMI)
+            n = own_idx[rank].numel()
+            send[: n * 3] = rgb3.index_select(0, own_idx[rank]).reshape(-1)
+            dist.gather(send, recv, dst=0)
+            if rank == 0:
+                for r in range(1, world):
+                    m = own_idx[r].numel()
+                    rgb3.index_copy_(0, own_idx[r], recv[r][: m * 3].view(-1, 3))
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ctx.reset_stats()
+    ctx.set_profiling(True)  # HIP events around every kernel launch, on the stream the kernels run on
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    ctx.set_profiling(False)
+
+    # per-kernel visit counts of exactly the same frames (deterministic), outside the timed region
+    accum2 = torch.zeros_like(accum)
+    rgb2 = torch.zeros_like(rgb)
+    ctx.reset_stats()
+    ctx.set_counting(True)
+    first = state["sample"] - args.steps * spp_per_step
+    for k in range(args.steps):
+        p = B.RenderParams(B.MODE_PATH, spp_per_step, first + k * spp_per_step, BOUNCES, SEED, rank, world, TILE_W, TILE_H)
+        ctx.render_device(cam, p, accum2.data_ptr(), rgb2.data_ptr())
+    ctx.synchronize()
+    cnt = ctx.stats()
+    ctx.set_counting(False)
+    assert cnt["rays_closest"] == st["rays_closest"] and cnt["rays_occluded"] == st["rays_occluded"]
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays = torch.tensor([float(st["rays_closest"] + st["rays_occluded"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed_max, total_rays = float(t.item()), float(rays.item())
+
+    if rank == 0:
+        def kernel_line(rays_k, visits, tests, ms, launches):
+            byts = algorithmic_bytes(rays_k, visits, tests)
+            return {"launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
+                    "algorithmic_bytes_per_launch": byts / max(launches, 1), "rays": int(rays_k),
+                    "node_visits_per_ray": visits / max(rays_k, 1), "tri_tests_per_ray": tests / max(rays_k, 1),
+                    "achieved_GBs": byts / max(ms, 1e-9) / 1e6, "algorithmic_bytes_per_ray": byts / max(rays_k, 1)}
+        kc = kernel_line(st["rays_closest"], cnt["node_visits_closest"], cnt["tri_tests_closest"], st["ms_closest"],
+                         st["launches_closest"])
+        ko = kernel_line(st["rays_occluded"], cnt["node_visits_occluded"], cnt["tri_tests_occluded"], st["ms_occluded"],
+                         st["launches_occluded"])
+        dom, dom_name = (kc, "k_trace_closest") if st["ms_closest"] >= st["ms_occluded"] else (ko, "k_trace_occluded")
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s, sponza-standin 1920x1080 path trace (ms_per_step = ms/frame @1spp per GPU)",
+            "value": total_rays / elapsed_max / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"sponza-standin ({len(arrays[3])} tris, procedural; sponza.obj absent) 1920x1080 "
+                                   f"path trace, {BOUNCES} bounces, 1 spp per GPU per step, procedural env "
+                                   f"(uffizi_probe.hdr absent), tiles {TILE_W}x{TILE_H} interleaved over {world} GPU(s), "
+                                   f"RCCL gather to rank 0" if world > 1 else
+                                   f"sponza-standin ({len(arrays[3])} tris, procedural; sponza.obj absent) 1920x1080 "
+                                   f"path trace, {BOUNCES} bounces, 1 spp per step, procedural env (uffizi_probe.hdr absent)",
+                       "resolution": [W, H], "bounces": BOUNCES, "spp_per_step": spp_per_step, "seed": SEED,
+                       "rays_per_step": total_rays / args.steps},
+            "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom_name,
+                         "per_kernel": {"k_trace_closest": kc, "k_trace_occluded": ko,
+                                        "other_ms_total": st["ms_other"], "other_launches": int(st["launches_other"])},
+                         "note": "achieved = algorithmic bytes (48 B/ray + 32 B/node visit + 36 B/triangle test) per "
+                                 "launch / average launch duration from HIP events in the timed region (rank 0)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(arrays, env, sf.SPONZA_LIGHT, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

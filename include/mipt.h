@@ -134,7 +134,9 @@ typedef struct mipt_stats {
     uint64_t rays_occluded;  /* rays given to the any-hit kernel */
     uint64_t launches_closest, launches_occluded, launches_other;
     double ms_closest, ms_occluded, ms_other; /* HIP-event time, only with profiling on */
-    uint64_t node_visits, tri_tests;          /* only with counting on */
+    /* only with counting on: box tests (node visits) and triangle tests, per traversal kernel */
+    uint64_t node_visits_closest, tri_tests_closest;
+    uint64_t node_visits_occluded, tri_tests_occluded;
 } mipt_stats;
 
 typedef struct mipt_mesh mipt_mesh;
@@ -256,6 +258,16 @@ int mipt_render_device(mipt_ctx* ctx, const mipt_camera* cam, const mipt_render_
                        float* rgb_dev);
 /* convenience: whole image to a HOST buffer (allocates, renders, copies back, synchronises) */
 int mipt_render(mipt_ctx* ctx, const mipt_camera* cam, const mipt_render_params* params, float* rgb_host);
+
+/* Device buffers for callers without a GPU allocator of their own (the
+ * frame readback of the reference, G:3213-3216, becomes mipt_buffer_download).
+ * All on the context's device; upload/download/zero are ordered on its stream
+ * and download synchronises. */
+int mipt_buffer_alloc(mipt_ctx* ctx, size_t bytes, void** dev_ptr);
+int mipt_buffer_free(mipt_ctx* ctx, void* dev_ptr);
+int mipt_buffer_zero(mipt_ctx* ctx, void* dev_ptr, size_t bytes);
+int mipt_buffer_upload(mipt_ctx* ctx, void* dev_ptr, const void* host_ptr, size_t bytes);
+int mipt_buffer_download(mipt_ctx* ctx, void* host_ptr, const void* dev_ptr, size_t bytes);
 
 int mipt_context_synchronize(mipt_ctx* ctx);
 /* profiling: HIP events around every kernel launch on the context's stream */

@@ -59,7 +59,8 @@ class Stats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_occluded", C.c_uint64),
                 ("launches_closest", C.c_uint64), ("launches_occluded", C.c_uint64), ("launches_other", C.c_uint64),
                 ("ms_closest", C.c_double), ("ms_occluded", C.c_double), ("ms_other", C.c_double),
-                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64)]
+                ("node_visits_closest", C.c_uint64), ("tri_tests_closest", C.c_uint64),
+                ("node_visits_occluded", C.c_uint64), ("tri_tests_occluded", C.c_uint64)]
 
 
 # every symbol include/mipt.h declares (tests check the library exports all of them)
@@ -77,6 +78,7 @@ SYMBOLS = [
     "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_destroy",
     "mipt_context_create", "mipt_context_destroy", "mipt_context_arena_bytes",
     "mipt_trace", "mipt_trace_device", "mipt_occluded", "mipt_eye_rays", "mipt_background",
+    "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
     "mipt_render_device", "mipt_render", "mipt_context_synchronize", "mipt_context_set_profiling",
     "mipt_context_set_counting", "mipt_context_get_stats", "mipt_context_reset_stats",
 ]
@@ -143,6 +145,11 @@ def lib():
     L.mipt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp]
     L.mipt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), fp]
     L.mipt_context_synchronize.argtypes = [vp]
+    L.mipt_buffer_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.mipt_buffer_free.argtypes = [vp, vp]
+    L.mipt_buffer_zero.argtypes = [vp, vp, C.c_size_t]
+    L.mipt_buffer_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.mipt_buffer_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.mipt_context_set_profiling.argtypes = [vp, C.c_int]
     L.mipt_context_set_counting.argtypes = [vp, C.c_int]
     L.mipt_context_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -459,6 +466,21 @@ class Context:
 
     def synchronize(self):
         check(lib().mipt_context_synchronize(self.h))
+
+    def buffer_alloc(self, nbytes, zero=True):
+        p = C.c_void_p()
+        check(lib().mipt_buffer_alloc(self.h, nbytes, C.byref(p)))
+        if zero:
+            check(lib().mipt_buffer_zero(self.h, p, nbytes))
+        return p.value
+
+    def buffer_free(self, ptr):
+        check(lib().mipt_buffer_free(self.h, C.c_void_p(ptr)))
+
+    def buffer_download(self, ptr, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        check(lib().mipt_buffer_download(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
+        return out
 
     def set_profiling(self, on):
         check(lib().mipt_context_set_profiling(self.h, int(on)))

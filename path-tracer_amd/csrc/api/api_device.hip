@@ -131,18 +131,17 @@ void count_launch(mipt_ctx* c, int cls) {
     else c->acc.launches_other++;
 }
 
-void trace_closest(mipt_ctx* c, const float4* rays, const int* index, const unsigned* countPtr, size_t nMax,
-                   float4* hits) {
+void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, float4* hits) {
     Timer t(c, 0);
     count_launch(c, 0);
-    launch_trace_closest(c->stream, c->ds, rays, index, countPtr, nMax, hits, c->counting ? c->dTotals + 2 : nullptr);
+    launch_trace_closest(c->stream, c->ds, rays, index, q, hits, c->counting ? c->dTotals + 2 : nullptr);
 }
-void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, const unsigned* countPtr, size_t nMax,
-                    unsigned char* occ) {
+void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueView q, unsigned char* occ) {
     Timer t(c, 1);
     count_launch(c, 1);
-    launch_trace_occluded(c->stream, c->ds, rays, target, countPtr, nMax, occ, c->counting ? c->dTotals + 4 : nullptr);
+    launch_trace_occluded(c->stream, c->ds, rays, target, q, occ, c->counting ? c->dTotals + 4 : nullptr);
 }
+QueueView dense(size_t n) { return QueueView{nullptr, 0u, (unsigned)n}; }
 
 int make_camera(const mipt_camera* cam, CameraDev& out) {
     if (!cam || cam->width <= 0 || cam->height <= 0 || cam->width > 32768 || cam->height > 32768)
@@ -337,6 +336,41 @@ void mipt_context_destroy(mipt_ctx* c) {
 
 size_t mipt_context_arena_bytes(const mipt_ctx* c) { return c ? c->arenaBytes : 0; }
 
+int mipt_buffer_alloc(mipt_ctx* c, size_t bytes, void** dev_ptr) {
+    if (!c || !dev_ptr || bytes == 0) return fail(MIPT_ERR_INVALID, "mipt_buffer_alloc: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(dev_ptr, bytes));
+    return MIPT_OK;
+}
+int mipt_buffer_free(mipt_ctx* c, void* dev_ptr) {
+    if (!c) return fail(MIPT_ERR_INVALID, "null context");
+    if (!dev_ptr) return MIPT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(dev_ptr));
+    return MIPT_OK;
+}
+int mipt_buffer_zero(mipt_ctx* c, void* dev_ptr, size_t bytes) {
+    if (!c || (bytes && !dev_ptr)) return fail(MIPT_ERR_INVALID, "mipt_buffer_zero: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (bytes) HIP_TRY(hipMemsetAsync(dev_ptr, 0, bytes, c->stream));
+    return MIPT_OK;
+}
+int mipt_buffer_upload(mipt_ctx* c, void* dev_ptr, const void* host_ptr, size_t bytes) {
+    if (!c || (bytes && (!dev_ptr || !host_ptr))) return fail(MIPT_ERR_INVALID, "mipt_buffer_upload: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (bytes) HIP_TRY(hipMemcpyAsync(dev_ptr, host_ptr, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MIPT_OK;
+}
+int mipt_buffer_download(mipt_ctx* c, void* host_ptr, const void* dev_ptr, size_t bytes) {
+    if (!c || (bytes && (!dev_ptr || !host_ptr))) return fail(MIPT_ERR_INVALID, "mipt_buffer_download: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (bytes) HIP_TRY(hipMemcpyAsync(host_ptr, dev_ptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MIPT_OK;
+}
+
 int mipt_context_synchronize(mipt_ctx* c) {
     if (!c) return fail(MIPT_ERR_INVALID, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -379,8 +413,10 @@ int mipt_context_get_stats(mipt_ctx* c, mipt_stats* out) {
     *out = c->acc;
     out->rays_closest += h[0];
     out->rays_occluded += h[1];
-    out->node_visits = h[2] + h[4];
-    out->tri_tests = h[3] + h[5];
+    out->node_visits_closest = h[2];
+    out->tri_tests_closest = h[3];
+    out->node_visits_occluded = h[4];
+    out->tri_tests_occluded = h[5];
     return MIPT_OK;
 }
 int mipt_context_reset_stats(mipt_ctx* c) {
@@ -398,7 +434,7 @@ int mipt_trace_device(mipt_ctx* c, const void* rays_dev, size_t n, void* hits_de
     if (n > 0x7fffffffu) return fail(MIPT_ERR_LIMIT, "mipt_trace_device: at most 2^31-1 rays per call");
     if (n == 0) return MIPT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    trace_closest(c, (const float4*)rays_dev, nullptr, nullptr, n, (float4*)hits_dev);
+    trace_closest(c, (const float4*)rays_dev, nullptr, dense(n), (float4*)hits_dev);
     c->acc.rays_closest += n;
     HIP_TRY(hipGetLastError());
     return MIPT_OK;
@@ -419,7 +455,7 @@ int mipt_trace(mipt_ctx* c, const float* ray_o, const float* ray_d, size_t n, fl
     if ((rc = c->sRays.ensure(rays.size() * sizeof(float4))) != MIPT_OK) return rc;
     if ((rc = c->sHits.ensure(n * sizeof(float4))) != MIPT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->sRays.p, rays.data(), rays.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    trace_closest(c, (const float4*)c->sRays.p, nullptr, nullptr, n, (float4*)c->sHits.p);
+    trace_closest(c, (const float4*)c->sRays.p, nullptr, dense(n), (float4*)c->sHits.p);
     c->acc.rays_closest += n;
     std::vector<float4> hits(n);
     HIP_TRY(hipMemcpyAsync(hits.data(), c->sHits.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
@@ -460,7 +496,7 @@ int mipt_occluded(mipt_ctx* c, const float* ray_o, const float* ray_d, const flo
     if ((rc = c->sAux.ensure(n)) != MIPT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->sRays.p, rays.data(), rays.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->sAux.p, 0, n, c->stream));
-    trace_occluded(c, (const float4*)c->sRays.p, nullptr, nullptr, n, (unsigned char*)c->sAux.p);
+    trace_occluded(c, (const float4*)c->sRays.p, nullptr, dense(n), (unsigned char*)c->sAux.p);
     c->acc.rays_occluded += n;
     HIP_TRY(hipMemcpyAsync(occluded, c->sAux.p, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -521,16 +557,18 @@ static int ensure_path_buffers(mipt_ctx* c, size_t cap) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
     const size_t f4 = sizeof(float4);
+    const size_t regionWaves = ((cap + 63) / 64 + kShards - 1) / kShards;
+    const size_t regionSize = regionWaves * 64, space = regionSize * kShards;  // >= cap
     const size_t oRays = take(2 * cap * f4), oHit = take(cap * f4), oMult = take(cap * f4), oCnst = take(cap * f4);
     const size_t oPend = take(cap * f4), oHm = take(cap * f4), oVP = take(cap * f4), oVN = take(cap * f4), oVT = take(cap * f4);
     const size_t oContrib = take(cap * nl * f4), oOcc = take(cap * nl), oKs = take(cap * 6 * f4), oPix = take(cap * 4);
-    const size_t oQ0 = take(cap * 4), oQ1 = take(cap * 4), oQA = take(cap * 4);
-    const size_t oSh = take(2 * cap * nl * f4), oShT = take(cap * nl * 4), oCnt = take((size_t)kMaxIter * 4 * 4);
+    const size_t oQ0 = take(space * 4), oQ1 = take(space * 4), oQA = take(space * 4);
+    const size_t oSh = take(2 * space * nl * f4), oShT = take(space * nl * 4), oCnt = take(kCounterWords * 4);
     int rc = c->pathMem.ensure(o);
     if (rc != MIPT_OK) { c->pb.capacity = 0; return rc; }
     unsigned char* b = (unsigned char*)c->pathMem.p;
     PathBuffers& pb = c->pb;
-    pb.capacity = cap; pb.nLights = nl;
+    pb.capacity = cap; pb.nLights = nl; pb.regionSize = (unsigned)regionSize; pb.space = (unsigned)space;
     pb.rays = (float4*)(b + oRays); pb.hit = (float4*)(b + oHit); pb.mult = (float4*)(b + oMult); pb.cnst = (float4*)(b + oCnst);
     pb.pendL = (float4*)(b + oPend); pb.hitMul = (float4*)(b + oHm); pb.vP = (float4*)(b + oVP); pb.vN = (float4*)(b + oVN);
     pb.vTex = (float4*)(b + oVT); pb.contrib = (float4*)(b + oContrib); pb.occ = b + oOcc; pb.ksStack = (float4*)(b + oKs);
@@ -569,7 +607,7 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
     }
     if (c->nOwnedTiles == 0) return MIPT_OK;
     const size_t cap = (size_t)c->nOwnedTiles * tileW * tileH;
-    if (cap > ((size_t)1 << 28)) return fail(MIPT_ERR_LIMIT, "more than 2^28 pixels in one partition");
+    if (cap > ((size_t)1 << 27)) return fail(MIPT_ERR_LIMIT, "more than 2^27 pixels in one partition");
     if ((rc = ensure_path_buffers(c, cap)) != MIPT_OK) return rc;
     const PathBuffers& pb = c->pb;
     const int nl = pb.nLights;
@@ -595,7 +633,7 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
     for (int sm = 0; sm < nSamples; sm++) {
         fp.sample = (unsigned)(rp->sample_offset + sm);
         fp.sampleCount = fp.sample + 1u;  // sampleCount++ before the loop, C:2232
-        HIP_TRY(hipMemsetAsync(pb.counters, 0, (size_t)kMaxIter * 4 * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(pb.counters, 0, kCounterWords * 4, c->stream));
         {
             Timer tm(c, 2);
             count_launch(c, 2);
@@ -603,23 +641,30 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
         }
         int itDone = 0;
         for (int it = 0; it <= lastIter; it++) {
-            trace_closest(c, pb.rays, pb.qExt[it & 1], &pb.counters[it * 4 + 0], cap, pb.hit);
+            trace_closest(c, pb.rays, pb.qExt[it & 1],
+                          QueueView{pb.counters + counter_index(it, 0, 0), pb.regionSize, pb.space}, pb.hit);
             {
                 Timer tm(c, 2);
                 count_launch(c, 2);
                 launch_shade_a(c->stream, c->ds, fp, pb, it);
             }
             if (rp->mode != MIPT_MODE_PRIMARY) {
-                trace_occluded(c, pb.shRays, pb.shTarget, &pb.counters[it * 4 + 2], cap * nl, pb.occ);
+                trace_occluded(c, pb.shRays, pb.shTarget,
+                               QueueView{pb.counters + counter_index(it, 2, 0), pb.regionSize * (unsigned)nl,
+                                         pb.space * (unsigned)nl}, pb.occ);
                 Timer tm(c, 2);
                 count_launch(c, 2);
                 launch_shade_b(c->stream, c->ds, fp, pb, it);
             }
             itDone = it + 1;
             if (unbounded && it >= 8 && (it & 3) == 0 && it < lastIter) {
-                unsigned next = 0;  // the reference has no bounce cap: stop when no path is left
-                HIP_TRY(hipMemcpyAsync(&next, &pb.counters[(it + 1) * 4], 4, hipMemcpyDeviceToHost, c->stream));
+                // the reference has no bounce cap: stop when no path is left
+                std::vector<unsigned> cnt((size_t)kShards * kCntStride);
+                HIP_TRY(hipMemcpyAsync(cnt.data(), pb.counters + counter_index(it + 1, 0, 0), cnt.size() * 4,
+                                       hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
+                unsigned long long next = 0;
+                for (int sh = 0; sh < kShards; sh++) next += cnt[(size_t)sh * kCntStride];
                 if (next == 0) break;
             }
         }

@@ -13,11 +13,34 @@ struct CameraDev;
 constexpr unsigned kMaxGrid = 8192;  // blocks; larger queues are grid-strided
 constexpr int kMaxLights = 16;
 constexpr int kMaxIter = 66;         // bounce iterations a frame can enqueue (counter slots)
+// Work queues are SHARDED: a returning atomic on one word runs at ~88/us on
+// MI355X, which a frame's 32k wavefront appends would saturate (measured:
+// 0.37 ms per 2M-item queue).  A queue is kShards regions of regionSize slots,
+// each with its own counter on its own 128-B line; the wavefront with index w
+// of a kernel's iteration space appends to shard w % kShards, so no region can
+// overflow.  Slot i of a queue is live iff (i % regionSize) < count[i / regionSize].
+constexpr int kShards = 64;
+constexpr int kCntStride = 32;       // unsigned words between two shard counters (128 B)
+constexpr int kQueuesPerIter = 3;    // 0 = extension, 1 = waiting Lambertian vertices, 2 = shadow rays
+
+__host__ __device__ inline size_t counter_index(int it, int queue, int shard) {
+    return (((size_t)it * kQueuesPerIter + queue) * kShards + shard) * kCntStride;
+}
+constexpr size_t kCounterWords = (size_t)kMaxIter * kQueuesPerIter * kShards * kCntStride;
+
+// a sharded queue as a kernel sees it; counts == nullptr means "dense, n items"
+struct QueueView {
+    const unsigned* counts;  // counter of shard 0; shard s at counts[s * kCntStride]
+    unsigned regionSize;     // slots per shard (multiple of 64)
+    unsigned space;          // kShards * regionSize, or the dense item count
+};
 
 // Per-path state of the wavefront integrator, SoA of float4 (16-B lane loads).
 // Index p = slot of the path inside this context's pixel partition.
 struct PathBuffers {
     size_t capacity;      // paths
+    unsigned regionSize;  // queue slots per shard = 64 * ceil(capacity / 64 / kShards)
+    unsigned space;       // kShards * regionSize: iteration space of every integrator kernel
     int nLights;
     float4* rays;         // [2p] = {o.xyz, tmin}, [2p+1] = {d.xyz, tmax}: extension ray of the path
     float4* hit;          // {bits(tri), t, beta, gamma}
@@ -36,7 +59,7 @@ struct PathBuffers {
     int* qAct;            // Lambertian vertices waiting for their shadow rays
     float4* shRays;       // shadow-ray queue, 2 float4 per ray
     int* shTarget;        // occ index each shadow ray reports to
-    unsigned* counters;   // [kMaxIter][4]: nExt, nAct, nShadow, pad
+    unsigned* counters;   // kCounterWords, see counter_index()
     unsigned long long* visitCounters;  // [2] closest: node visits, tri tests; [2] occluded
 };
 
@@ -50,10 +73,10 @@ struct FrameParams {
     float* rgb;
 };
 
-void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index,
-                          const unsigned* countPtr, size_t nMax, float4* hits, unsigned long long* counters);
-void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target,
-                           const unsigned* countPtr, size_t nMax, unsigned char* occ, unsigned long long* counters);
+void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
+                          float4* hits, unsigned long long* counters);
+void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
+                           unsigned char* occ, unsigned long long* counters);
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays);
 void launch_resolve_hits(hipStream_t st, const DevScene& s, const float4* rays, const float4* hits, size_t n,
                          float* out);

@@ -18,20 +18,32 @@
 
 namespace ptd {
 
-enum : int { FLAG_NEGD = 1 };  // currDir / viewDir of the vertex is -ray.d
+enum : int { FLAG_NEGD = 1,        // currDir / viewDir of the vertex is -ray.d
+             FLAG_FROM_METAL = 2 };  // direct mode: the ray was shot by a metal vertex
 enum : int { MISS_LAMBERT = 0, MISS_SPECULAR = 1 };
 constexpr float kFltMax = 3.402823466e+38f;
 
-// slot for each lane whose pred is set; one atomicAdd per wavefront
-__device__ __forceinline__ unsigned wave_append(unsigned* counter, bool pred) {
+// Queue slot for each lane whose pred is set: ballot + popcount, ONE atomicAdd
+// per wavefront, on the counter of the shard this wavefront feeds.
+// Shard rule (keeps every region within regionSize): a kernel that consumes
+// the extension queue (generate, shade_a) feeds shard (wavefront index) %
+// kShards; shade_b, which consumes qAct, feeds the shard its slot lies in, so
+// the paths that reach next iteration's extension shard s are exactly those
+// that shade_a wavefronts = s (mod kShards) handled: at most regionSize.
+__device__ __forceinline__ unsigned wave_append(unsigned* shard0, unsigned regionSize, unsigned shard, bool pred) {
     const unsigned long long mask = __ballot(pred);
     if (mask == 0ull) return 0u;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)mask) - 1;
     unsigned base = 0;
-    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
+    if (lane == leader) base = atomicAdd(shard0 + (size_t)shard * kCntStride, (unsigned)__popcll(mask));
     base = __shfl(base, leader);
-    return base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    return shard * regionSize + base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+}
+// is slot i of a sharded queue live?
+__device__ __forceinline__ bool slot_live(const unsigned* shard0, unsigned regionSize, unsigned i) {
+    const unsigned sh = i / regionSize;
+    return (i - sh * regionSize) < shard0[(size_t)sh * kCntStride];
 }
 
 __device__ __forceinline__ vec3 xyz(const float4 v) { return vec3{v.x, v.y, v.z}; }
@@ -55,8 +67,7 @@ __device__ __forceinline__ void write_pixel(const FrameParams& fp, int pix, cons
 __global__ __launch_bounds__(kBlock) void k_generate(CameraDev cam, FrameParams fp, PathBuffers pb) {
     const unsigned tilePix = (unsigned)(fp.tileW * fp.tileH);
     const unsigned n = (unsigned)fp.nOwnedTiles * tilePix;
-    const unsigned nRound = (n + 63u) & ~63u;
-    for (unsigned p = blockIdx.x * kBlock + threadIdx.x; p < nRound; p += gridDim.x * kBlock) {
+    for (unsigned p = blockIdx.x * kBlock + threadIdx.x; p < pb.space; p += gridDim.x * kBlock) {
         bool valid = p < n;
         int pix = -1;
         if (valid) {
@@ -78,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(CameraDev cam, FrameParams 
             }
             pb.pixel[p] = pix;
         }
-        const unsigned slot = wave_append(&pb.counters[0], valid);
+        const unsigned slot = wave_append(pb.counters + counter_index(0, 0, 0), pb.regionSize, (p >> 6) % (unsigned)kShards, valid);
         if (valid) pb.qExt[0][slot] = (int)p;
     }
 }
@@ -91,18 +102,17 @@ __device__ __forceinline__ void emit_extension(const PathBuffers& pb, unsigned p
 
 // ---- path mode ----
 __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams fp, PathBuffers pb, int it) {
-    const unsigned n = pb.counters[it * 4 + 0];
-    const unsigned nRound = (n + 63u) & ~63u;
+    const unsigned* cCur = pb.counters + counter_index(it, 0, 0);
     const int* q = pb.qExt[it & 1];
     int* qNext = pb.qExt[(it + 1) & 1];
-    unsigned* cNext = &pb.counters[(it + 1) * 4 + 0];
-    unsigned* cAct = &pb.counters[it * 4 + 1];
-    unsigned* cSh = &pb.counters[it * 4 + 2];
+    unsigned* cNext = pb.counters + counter_index(it + 1, 0, 0);
+    unsigned* cAct = pb.counters + counter_index(it, 1, 0);
+    unsigned* cSh = pb.counters + counter_index(it, 2, 0);
     const int nl = pb.nLights;
     const bool capped = (fp.maxBounces >= 0) && (it >= fp.maxBounces);
 
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nRound; i += gridDim.x * kBlock) {
-        const bool valid = i < n;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < pb.space; i += gridDim.x * kBlock) {
+        const bool valid = slot_live(cCur, pb.regionSize, i);
         bool toExt = false, toAct = false;
         unsigned p = 0;
         int pix = 0;
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
                         pb.occ[(size_t)p * nl + k] = 0;
                         // shadow ray P -> light, (0, dist), C:2303 / C:2428; the lanes here are
                         // exactly the Lambertian vertices, the ballot sees only them
-                        const unsigned sl = wave_append(cSh, need);
+                        const unsigned sl = wave_append(cSh, pb.regionSize * (unsigned)nl, (i >> 6) % (unsigned)kShards, need);
                         if (need) {
                             pb.shRays[2 * (size_t)sl] = pack(P, 0.0f);
                             pb.shRays[2 * (size_t)sl + 1] = pack(pt::normalize(l), sqrtf(falloff));
@@ -213,23 +223,22 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
                 }
             }
         }
-        const unsigned sExt = wave_append(cNext, toExt);
+        const unsigned sExt = wave_append(cNext, pb.regionSize, (i >> 6) % (unsigned)kShards, toExt);
         if (toExt) qNext[sExt] = (int)p;
-        const unsigned sAct = wave_append(cAct, toAct);
+        const unsigned sAct = wave_append(cAct, pb.regionSize, (i >> 6) % (unsigned)kShards, toAct);
         if (toAct) pb.qAct[sAct] = (int)p;
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_shade_b_path(DevScene s, FrameParams fp, PathBuffers pb, int it) {
-    const unsigned n = pb.counters[it * 4 + 1];
-    const unsigned nRound = (n + 63u) & ~63u;
+    const unsigned* cCur = pb.counters + counter_index(it, 1, 0);
     int* qNext = pb.qExt[(it + 1) & 1];
-    unsigned* cNext = &pb.counters[(it + 1) * 4 + 0];
+    unsigned* cNext = pb.counters + counter_index(it + 1, 0, 0);
     const int nl = pb.nLights;
     const bool capped = (fp.maxBounces >= 0) && (it >= fp.maxBounces);
 
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nRound; i += gridDim.x * kBlock) {
-        const bool valid = i < n;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < pb.space; i += gridDim.x * kBlock) {
+        const bool valid = slot_live(cCur, pb.regionSize, i);
         bool toExt = false;
         unsigned p = 0;
         if (valid) {
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_b_path(DevScene s, FrameParams
                 toExt = true;
             }
         }
-        const unsigned sExt = wave_append(cNext, toExt);
+        const unsigned sExt = wave_append(cNext, pb.regionSize, i / pb.regionSize, toExt);
         if (toExt) qNext[sExt] = (int)p;
     }
 }
@@ -279,18 +288,17 @@ __device__ __forceinline__ vec3 unwind_metal(const PathBuffers& pb, unsigned p, 
 }
 
 __global__ __launch_bounds__(kBlock) void k_shade_a_direct(DevScene s, FrameParams fp, PathBuffers pb, int it) {
-    const unsigned n = pb.counters[it * 4 + 0];
-    const unsigned nRound = (n + 63u) & ~63u;
+    const unsigned* cCur = pb.counters + counter_index(it, 0, 0);
     const int* q = pb.qExt[it & 1];
     int* qNext = pb.qExt[(it + 1) & 1];
-    unsigned* cNext = &pb.counters[(it + 1) * 4 + 0];
-    unsigned* cAct = &pb.counters[it * 4 + 1];
-    unsigned* cSh = &pb.counters[it * 4 + 2];
+    unsigned* cNext = pb.counters + counter_index(it + 1, 0, 0);
+    unsigned* cAct = pb.counters + counter_index(it, 1, 0);
+    unsigned* cSh = pb.counters + counter_index(it, 2, 0);
     const int nl = pb.nLights;
     const int level = it;
 
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nRound; i += gridDim.x * kBlock) {
-        const bool valid = i < n;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < pb.space; i += gridDim.x * kBlock) {
+        const bool valid = slot_live(cCur, pb.regionSize, i);
         bool toExt = false, toAct = false;
         unsigned p = 0;
         vec3 P{0, 0, 0};
@@ -308,8 +316,10 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_direct(DevScene s, FramePara
                 flags = f2i(c4.w) & 0xff;
                 depth = f2i(c4.w) >> 8;
             }
-            if (tri < 0) {  // C:2212, C:2462, C:2478, C:2488: always the background at -d
-                write_pixel(fp, pix, unwind_metal(pb, p, depth, get_background(s, -d)));
+            if (tri < 0) {  // C:2212, C:2462, C:2478, C:2488: always the background at -d; a metal
+                            // vertex returns it WITHOUT its own Ks (C:2461-2462)
+                const int applied = depth - ((flags & FLAG_FROM_METAL) ? 1 : 0);
+                write_pixel(fp, pix, unwind_metal(pb, p, applied, get_background(s, -d)));
             } else if (fp.mode == 0) {  // primary only: (t, triangle id, material)
                 const HitInfo hi = reconstruct_hit(s, tri, h.y, h.z, h.w, d);
                 write_pixel(fp, pix, vec3{h.y, (float)tri, (float)hi.material});
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_direct(DevScene s, FramePara
                         pb.occ[(size_t)p * nl + k] = 0;
                         // shadow ray P -> light, (0, dist), C:2303 / C:2428; the lanes here are
                         // exactly the Lambertian vertices, the ballot sees only them
-                        const unsigned sl = wave_append(cSh, need);
+                        const unsigned sl = wave_append(cSh, pb.regionSize * (unsigned)nl, (i >> 6) % (unsigned)kShards, need);
                         if (need) {
                             pb.shRays[2 * (size_t)sl] = pack(P, 0.0f);
                             pb.shRays[2 * (size_t)sl + 1] = pack(pt::normalize(l), sqrtf(falloff));
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_direct(DevScene s, FramePara
                         const vec3 reflected = mirror(-viewDir, N);  // C:2459
                         emit_extension(pb, p, P, 0.001f, reflected);
                         pb.ksStack[(size_t)p * 6 + depth] = pack(m.Ks, 0.0f);
-                        pb.cnst[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(0 | ((depth + 1) << 8)));
+                        pb.cnst[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(FLAG_FROM_METAL | ((depth + 1) << 8)));
                         pb.mult[p] = make_float4(1.0f, 1.0f, 1.0f, eta);
                         toExt = true;
                     }
@@ -379,17 +389,18 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_direct(DevScene s, FramePara
                 }
             }
         }
-        const unsigned sExt = wave_append(cNext, toExt);
+        const unsigned sExt = wave_append(cNext, pb.regionSize, (i >> 6) % (unsigned)kShards, toExt);
         if (toExt) qNext[sExt] = (int)p;
-        const unsigned sAct = wave_append(cAct, toAct);
+        const unsigned sAct = wave_append(cAct, pb.regionSize, (i >> 6) % (unsigned)kShards, toAct);
         if (toAct) pb.qAct[sAct] = (int)p;
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_shade_b_direct(DevScene s, FrameParams fp, PathBuffers pb, int it) {
-    const unsigned n = pb.counters[it * 4 + 1];
+    const unsigned* cCur = pb.counters + counter_index(it, 1, 0);
     const int nl = pb.nLights;
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < pb.space; i += gridDim.x * kBlock) {
+        if (!slot_live(cCur, pb.regionSize, i)) continue;
         const unsigned p = (unsigned)pb.qAct[i];
         const int pix = pb.pixel[p];
         const vec3 brdf = xyz(pb.vTex[p]);
@@ -408,10 +419,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_b_direct(DevScene s, FramePara
 __global__ void k_fold_counters(const unsigned* __restrict__ counters, int nIter, unsigned long long* totals) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         unsigned long long e = 0, sh = 0;
-        for (int it = 0; it < nIter; it++) {
-            e += counters[it * 4 + 0];
-            sh += counters[it * 4 + 2];
-        }
+        for (int it = 0; it < nIter; it++)
+            for (int s = 0; s < kShards; s++) {
+                e += counters[counter_index(it, 0, s)];
+                sh += counters[counter_index(it, 2, s)];
+            }
         totals[0] += e;
         totals[1] += sh;
     }
@@ -426,16 +438,15 @@ static inline unsigned grid_for(size_t n) {
 }
 
 void launch_generate(hipStream_t st, const CameraDev& cam, const FrameParams& fp, const PathBuffers& pb) {
-    const size_t n = (size_t)fp.nOwnedTiles * fp.tileW * fp.tileH;
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(n)), dim3(kBlock), 0, st, cam, fp, pb);
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(pb.space)), dim3(kBlock), 0, st, cam, fp, pb);
 }
 void launch_shade_a(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter) {
-    const unsigned g = grid_for(pb.capacity);
+    const unsigned g = grid_for(pb.space);
     if (fp.mode == 2) hipLaunchKernelGGL(k_shade_a_path, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
     else hipLaunchKernelGGL(k_shade_a_direct, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
 }
 void launch_shade_b(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter) {
-    const unsigned g = grid_for(pb.capacity);
+    const unsigned g = grid_for(pb.space);
     if (fp.mode == 2) hipLaunchKernelGGL(k_shade_b_path, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
     else hipLaunchKernelGGL(k_shade_b_direct, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
 }

@@ -13,13 +13,15 @@ namespace ptd {
 // rays: 2 float4 per ray; index (nullable) maps queue slot -> ray/hit slot.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene s, const float4* __restrict__ rays,
-                                                          const int* __restrict__ index,
-                                                          const unsigned* __restrict__ countPtr, unsigned nStatic,
+                                                          const int* __restrict__ index, QueueView q,
                                                           float4* __restrict__ hits,
                                                           unsigned long long* __restrict__ counters) {
-    const unsigned n = countPtr ? *countPtr : nStatic;
     unsigned nv = 0, nt = 0;
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < q.space; i += gridDim.x * kBlock) {
+        if (q.counts) {  // sharded queue: slot i is live iff it lies below its shard's counter
+            const unsigned sh = i / q.regionSize;
+            if (i - sh * q.regionSize >= q.counts[(size_t)sh * kCntStride]) continue;
+        }
         const unsigned p = index ? (unsigned)index[i] : i;
         const float4 r0 = rays[2 * (size_t)p], r1 = rays[2 * (size_t)p + 1];
         const Hit h = walk<false, COUNT>(s.nodes, s.leafTris, vec3{r0.x, r0.y, r0.z}, vec3{r1.x, r1.y, r1.z}, r0.w,
@@ -42,13 +44,15 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene s, const floa
 // any-hit: occ[target[i]] = 1 when occluded (never writes 0: the caller clears)
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_occluded(DevScene s, const float4* __restrict__ rays,
-                                                           const int* __restrict__ target,
-                                                           const unsigned* __restrict__ countPtr, unsigned nStatic,
+                                                           const int* __restrict__ target, QueueView q,
                                                            unsigned char* __restrict__ occ,
                                                            unsigned long long* __restrict__ counters) {
-    const unsigned n = countPtr ? *countPtr : nStatic;
     unsigned nv = 0, nt = 0;
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < q.space; i += gridDim.x * kBlock) {
+        if (q.counts) {
+            const unsigned sh = i / q.regionSize;
+            if (i - sh * q.regionSize >= q.counts[(size_t)sh * kCntStride]) continue;
+        }
         const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
         const Hit h = walk<true, COUNT>(s.nodes, s.leafTris, vec3{r0.x, r0.y, r0.z}, vec3{r1.x, r1.y, r1.z}, r0.w, r1.w,
                                         nv, nt);
@@ -118,25 +122,21 @@ static inline unsigned grid_for(size_t n) {
     return (unsigned)g;
 }
 
-void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index,
-                          const unsigned* countPtr, size_t nMax, float4* hits, unsigned long long* counters) {
-    const unsigned g = grid_for(nMax);
+void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
+                          float4* hits, unsigned long long* counters) {
+    const unsigned g = grid_for(q.space);
     if (counters)
-        hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(kBlock), 0, st, s, rays, index, countPtr, (unsigned)nMax,
-                           hits, counters);
+        hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(kBlock), 0, st, s, rays, index, q, hits, counters);
     else
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(kBlock), 0, st, s, rays, index, countPtr,
-                           (unsigned)nMax, hits, counters);
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(kBlock), 0, st, s, rays, index, q, hits, counters);
 }
-void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target,
-                           const unsigned* countPtr, size_t nMax, unsigned char* occ, unsigned long long* counters) {
-    const unsigned g = grid_for(nMax);
+void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
+                           unsigned char* occ, unsigned long long* counters) {
+    const unsigned g = grid_for(q.space);
     if (counters)
-        hipLaunchKernelGGL(k_trace_occluded<true>, dim3(g), dim3(kBlock), 0, st, s, rays, target, countPtr,
-                           (unsigned)nMax, occ, counters);
+        hipLaunchKernelGGL(k_trace_occluded<true>, dim3(g), dim3(kBlock), 0, st, s, rays, target, q, occ, counters);
     else
-        hipLaunchKernelGGL(k_trace_occluded<false>, dim3(g), dim3(kBlock), 0, st, s, rays, target, countPtr,
-                           (unsigned)nMax, occ, counters);
+        hipLaunchKernelGGL(k_trace_occluded<false>, dim3(g), dim3(kBlock), 0, st, s, rays, target, q, occ, counters);
 }
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays) {
     hipLaunchKernelGGL(k_eye_rays, dim3(grid_for(count)), dim3(kBlock), 0, st, cam, first, (unsigned)count, rays);

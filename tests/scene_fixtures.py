@@ -122,7 +122,7 @@ def sponza_standin(detail=1):
 
     X, Y, Z = 1.6, 1.3, 0.9  # half extents; atrium spans [-X,X] x [-Y/2.., ] ...
     y0, y1 = -0.6, 0.9
-    n = 24 * detail
+    n = 32 * detail
     quad((-X, y0, Z), (X, y0, Z), (X, y0, -Z), (-X, y0, -Z), 0, n, n)              # floor
     quad((-X, y0, -Z), (X, y0, -Z), (X, y1, -Z), (-X, y1, -Z), 1, n, n // 2)       # back wall
     quad((X, y0, Z), (-X, y0, Z), (-X, y1, Z), (X, y1, Z), 1, n, n // 2)           # front wall (behind camera)
@@ -136,14 +136,14 @@ def sponza_standin(detail=1):
     quad((sx, y1, -sz), (X, y1, -sz), (X, y1, sz), (sx, y1, sz), 1, n // 4, n // 4)
     # two storeys of colonnades along both long sides
     ncol = 8
-    seg, rings = 16 * detail, 12 * detail
+    seg, rings = 24 * detail, 24 * detail
     for storey, (ya, yb) in enumerate(((y0, 0.1), (0.18, 0.8))):
         for side, zc in enumerate((-0.55, 0.55)):
             xs = np.linspace(-1.35, 1.35, ncol)
             for cx in xs:
                 column(cx, zc, ya, yb, 0.055 - 0.012 * storey, seg, rings, 4)
             for k in range(ncol - 1):
-                arch(xs[k] + 0.05, xs[k + 1] - 0.05, zc, yb - 0.12, 0.6, 0.06, 12 * detail, 1)
+                arch(xs[k] + 0.05, xs[k + 1] - 0.05, zc, yb - 0.12, 0.6, 0.06, 24 * detail, 1)
         # gallery floor slab of the upper storey
         if storey == 0:
             quad((-X, 0.1, -Z), (X, 0.1, -Z), (X, 0.1, -0.5), (-X, 0.1, -0.5), 1, n, n // 6)
@@ -152,7 +152,7 @@ def sponza_standin(detail=1):
             quad((-X, 0.18, Z), (X, 0.18, Z), (X, 0.18, 0.5), (-X, 0.18, 0.5), 1, n, n // 6)
     # drapes: sinusoidally folded cloth hanging from the gallery
     for dk, (xc, col) in enumerate(((-0.8, 5), (0.0, 2), (0.8, 3))):
-        nu, nv = 48 * detail, 24 * detail
+        nu, nv = 72 * detail, 40 * detail
         for iu in range(nu):
             for iv in range(nv):
                 def D(u, v):

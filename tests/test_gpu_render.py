@@ -1,0 +1,144 @@
+"""GPU parity of the integrators through the C-ABI.
+
+Tolerances (north_star: "within a stated per-pixel RMSE and mean-radiance
+tolerance at equal spp with matched seeds"), against the CPU oracle run with
+the same counter RNG:
+  direct mode (shade):           RMSE <= 1e-5 * mean, |d mean| <= 1e-6 * mean   (observed: bit-identical)
+  path mode (shade_pathtrace):   RMSE <= 5e-3 * mean, |d mean| <= 1e-4 * mean
+The only arithmetic that differs between the two sides is acosf/sinf/cosf
+(device library vs glibc, ~1 ulp): most pixels agree to 1e-7, and a few paths
+per image flip at a discontinuity (a shadow edge, Russian roulette, total
+internal reflection), which is what the RMSE bound leaves room for.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_cache = {}
+
+
+def setup_scene(B, sf, name, lights=None):
+    if name not in _cache:
+        arrays = sf.load_scene_arrays(name) if name != "sponza" else sf.sponza_standin(1)
+        env = sf.procedural_env(128)
+        lights = lights or (sf.SPONZA_LIGHT if name == "sponza" else sf.DEFAULT_LIGHT)
+        scene = sf.product_scene_from_mesh_arrays(*arrays, env=env, lights=lights)
+        ctx = B.Context(scene, device=0)
+        orc = sf.oracle_scene_from_mesh_arrays(*arrays, env=env, lights=lights)
+        _cache[name] = (scene, ctx, orc)
+    return _cache[name]
+
+
+def cams(B, ob, sf, name, w, h):
+    if name == "sponza":
+        return B.make_camera(w, h, sf.SPONZA_EYE, sf.SPONZA_LOOKAT), ob.make_camera(w, h, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
+    return B.default_camera(w, h), ob.make_camera(w, h)
+
+
+def compare(img, ref, rmse_tol, mean_tol):
+    assert not np.isnan(img).any()
+    mean = float(ref.astype(np.float64).mean())
+    rmse = float(np.sqrt(np.mean((img.astype(np.float64) - ref) ** 2)))
+    dmean = abs(float(img.astype(np.float64).mean()) - mean)
+    assert rmse <= rmse_tol * mean, (rmse / mean, "relative RMSE")
+    assert dmean <= mean_tol * mean, (dmean / mean, "relative mean-radiance difference")
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "cornellbox-metal", "cornellbox-glass", "teapot-glass", "testObj",
+                                  "bunny", "textured", "sponza"])
+def test_direct_mode_vs_oracle(B, ob, sf, name):
+    """Scene::Raytrace + shade (cs488.h:2200-2229, 2402-2496): config 2 of BASELINE.json at reduced size"""
+    scene, ctx, orc = setup_scene(B, sf, name)
+    cam, ocam = cams(B, ob, sf, name, 256, 192)
+    compare(ctx.render(cam, mode=B.MODE_DIRECT), orc.raytrace(ocam), 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("name,spp,bounces", [("cornellbox", 4, 4), ("cornellbox-metal", 4, 4), ("cornellbox-glass", 4, 8),
+                                              ("teapot-glass", 2, 8), ("testObj", 2, 4), ("bunny", 2, 4),
+                                              ("sponza", 2, 4), ("cornellbox", 2, 12), ("cornellbox-glass", 1, -1)])
+def test_path_mode_vs_oracle(B, ob, sf, name, spp, bounces):
+    """Scene::Pathtrace + shade_pathtrace (cs488.h:2230-2261, 2267-2397), matched seeds and spp"""
+    scene, ctx, orc = setup_scene(B, sf, name)
+    cam, ocam = cams(B, ob, sf, name, 256, 192)
+    img = ctx.render(cam, mode=B.MODE_PATH, spp=spp, max_bounces=bounces, seed=5)
+    ref = orc.pathtrace(ocam, spp=spp, max_bounces=bounces, rng_mode=1, seed=5)
+    compare(img, ref, 5e-3, 1e-4)
+    # ray counts agree up to the handful of flipped paths
+    st = ctx.stats()
+    assert st["rays_closest"] + st["rays_occluded"] > 0
+
+
+def test_ray_counts_match_oracle(B, ob, sf):
+    scene, ctx, orc = setup_scene(B, sf, "cornellbox")
+    cam, ocam = cams(B, ob, sf, "cornellbox", 128, 96)
+    ctx.reset_stats()
+    ctx.render(cam, mode=B.MODE_PATH, spp=1, max_bounces=4, seed=2)
+    st = ctx.stats()
+    orc.pathtrace(ocam, spp=1, max_bounces=4, rng_mode=1, seed=2)
+    got = st["rays_closest"] + st["rays_occluded"]
+    assert abs(got - orc.last_rays) <= 1e-3 * orc.last_rays, (got, orc.last_rays)
+
+
+def test_partition_union_is_bit_identical(B, ob, sf):
+    """multi-GPU correctness: the image assembled from N tile partitions equals the 1-partition image bit for bit
+    (the RNG is keyed on the global pixel index, not on the partition)"""
+    scene, ctx, orc = setup_scene(B, sf, "cornellbox-glass")
+    cam = B.default_camera(200, 120)  # not a multiple of the tile size: exercises ragged edge tiles
+    whole = ctx.render(cam, mode=B.MODE_PATH, spp=2, max_bounces=4, seed=9)
+    for parts in (2, 3, 8):
+        acc = np.zeros_like(whole)
+        owned = np.zeros(whole.shape[:2], bool)
+        for r in range(parts):
+            part = ctx.render(cam, mode=B.MODE_PATH, spp=2, max_bounces=4, seed=9, part_index=r, part_count=parts)
+            mask = np.any(part != 0, axis=2)
+            assert not np.any(mask & owned), "two partitions wrote the same pixel"
+            owned |= mask
+            acc += part
+        assert np.array_equal(acc.view(np.uint32), whole.view(np.uint32))
+
+
+def test_progressive_equals_one_shot(B, ob, sf):
+    """accumulation buffer + sample_offset carry a progressive render: 2 + 3 samples == 5 samples, bitwise"""
+    scene, ctx, orc = setup_scene(B, sf, "cornellbox")
+    cam = B.default_camera(128, 96)
+    one = ctx.render(cam, mode=B.MODE_PATH, spp=5, max_bounces=4, seed=4)
+    n = 96 * 128 * 3 * 4
+    acc, rgb = ctx.buffer_alloc(n), ctx.buffer_alloc(n)
+    for off, k in ((0, 2), (2, 3)):
+        ctx.render_device(cam, B.RenderParams(B.MODE_PATH, k, off, 4, 4, 0, 1, 0, 0), acc, rgb)
+    got = ctx.buffer_download(rgb, (96, 128, 3))
+    ctx.buffer_free(acc)
+    ctx.buffer_free(rgb)
+    assert np.array_equal(got.view(np.uint32), one.view(np.uint32))
+
+
+def test_background_lookup(B, ob, sf):
+    """Scene::getBackground (cs488.h:2038-2053): nearest lookup, so an acosf ulp can move a direction on a texel
+    border to the neighbour: >= 99.9 % identical texels, the rest adjacent"""
+    scene, ctx, orc = setup_scene(B, sf, "cornellbox")
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=(100000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    d[:6] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, 1, 0], [-1, 0, 0], [0, -1, 0]]  # incl. the NaN cases (xy = 0)
+    a, b = ctx.background(d), orc.background(d)
+    same = np.all(a.view(np.uint32) == b.view(np.uint32), axis=1)
+    assert same.mean() >= 0.999
+    assert same[:6].all()
+
+
+def test_primary_mode_and_errors(B, ob, sf):
+    scene, ctx, orc = setup_scene(B, sf, "cornellbox")
+    cam, ocam = cams(B, ob, sf, "cornellbox", 64, 48)
+    img = ctx.render(cam, mode=B.MODE_PRIMARY)
+    o, d = orc.eye_rays(ocam)
+    tri, t, _ = orc.intersect(o, d)
+    hit = tri >= 0
+    assert np.array_equal(img.reshape(-1, 3)[hit, 1].astype(np.int32), tri[hit])
+    assert np.array_equal(img.reshape(-1, 3)[hit, 0].view(np.uint32), t[hit].view(np.uint32))
+    with pytest.raises(B.MiptError):
+        ctx.render(cam, mode=7)
+    with pytest.raises(B.MiptError):
+        ctx.render(cam, mode=B.MODE_PATH, spp=1, tile_w=12)
+    with pytest.raises(B.MiptError):
+        ctx.render(B.default_camera(0, 10), mode=B.MODE_DIRECT)
