@@ -80,7 +80,8 @@ def main():
     import torch
     import torch.distributed as dist
     import scene_fixtures as sf
-    B = importlib.import_module("path-tracer_amd").binding
+    pkg = importlib.import_module("path-tracer_amd")
+    B = pkg.binding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -104,17 +105,7 @@ def main():
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
     rgb = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
 
-    # pixels this rank owns (same rule as mipt_render_params: (tx + 3*ty) % parts == part), for the gather
-    tiles_x, tiles_y = (W + TILE_W - 1) // TILE_W, (H + TILE_H - 1) // TILE_H
-    ty, tx = np.meshgrid(np.arange(tiles_y), np.arange(tiles_x), indexing="ij")
-    owner_of_tile = (tx + 3 * ty) % world
-    py, px = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
-    owner = owner_of_tile[py // TILE_H, px // TILE_W]
-    own_idx = [torch.from_numpy(np.flatnonzero(owner.reshape(-1) == r)).to(dev) for r in range(world)]
-    max_own = max(int(i.numel()) for i in own_idx)
-    send = torch.zeros(max_own * 3, dtype=torch.float32, device=dev)
-    recv = [torch.zeros(max_own * 3, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
-    rgb3 = rgb.view(-1, 3)
+    gatherer = pkg.tiles.TileGather(W, H, rank, world, dev, TILE_W, TILE_H)  # owned pixels -> rank 0, one RCCL gather per step
 
     spp_per_step = world  # one frame-equivalent of paths per GPU per step
     state = {"sample": 0}
@@ -123,14 +114,7 @@ def main():
         p = B.RenderParams(B.MODE_PATH, spp_per_step, state["sample"], BOUNCES, SEED, rank, world, TILE_W, TILE_H)
         ctx.render_device(cam, p, accum.data_ptr(), rgb.data_ptr())
         state["sample"] += spp_per_step
-        if world > 1:  # tiles -> rank 0 (RCCL gather over xGMI)
-            n = own_idx[rank].numel()
-            send[: n * 3] = rgb3.index_select(0, own_idx[rank]).reshape(-1)
-            dist.gather(send, recv, dst=0)
-            if rank == 0:
-                for r in range(1, world):
-                    m = own_idx[r].numel()
-                    rgb3.index_copy_(0, own_idx[r], recv[r][: m * 3].view(-1, 3))
+        gatherer.gather(rgb)  # no-op on one GPU
 
     def sync():
         torch.cuda.synchronize(dev)

@@ -1,0 +1,61 @@
+"""Image-tile partition across the GPUs of one node and the gather of the
+tiles to rank 0 (north_star subsystem 4).  The scene is replicated per GPU;
+each rank renders the tiles it owns (mipt_render_params.part_index/part_count)
+into its own frame buffer; ONE collective per step moves the owned pixels to
+rank 0: torch.distributed.gather, which is RCCL over xGMI with backend "nccl".
+No all-reduce: a ring all-reduce of full frames would be per-link bound and
+move N times the bytes for nothing.
+
+Ownership rule (same as the C library, api_device.hip): tile (tx, ty) of
+tile_w x tile_h pixels belongs to part (tx + 3*ty) % parts.
+"""
+import numpy as np
+
+TILE_W, TILE_H = 64, 8
+
+
+def tile_owner_map(width, height, parts, tile_w=TILE_W, tile_h=TILE_H):
+    """(height, width) int array: the part that renders each pixel"""
+    tiles_x, tiles_y = (width + tile_w - 1) // tile_w, (height + tile_h - 1) // tile_h
+    ty, tx = np.meshgrid(np.arange(tiles_y), np.arange(tiles_x), indexing="ij")
+    owner_of_tile = (tx + 3 * ty) % max(1, parts)
+    py, px = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    return owner_of_tile[py // tile_h, px // tile_w]
+
+
+def owned_pixel_indices(width, height, parts, tile_w=TILE_W, tile_h=TILE_H):
+    """list over parts of sorted flat pixel indices (row-major, origin bottom-left like the frame buffer)"""
+    owner = tile_owner_map(width, height, parts, tile_w, tile_h).reshape(-1)
+    return [np.flatnonzero(owner == r) for r in range(max(1, parts))]
+
+
+class TileGather:
+    """Pre-allocated buffers + index tensors for the per-step gather."""
+
+    def __init__(self, width, height, rank, world, device, tile_w=TILE_W, tile_h=TILE_H):
+        import torch
+        self.rank, self.world = rank, world
+        self.idx = [torch.from_numpy(i).to(device) for i in owned_pixel_indices(width, height, world, tile_w, tile_h)]
+        self.max_own = max(int(i.numel()) for i in self.idx)
+        self.send = torch.zeros(self.max_own * 3, dtype=torch.float32, device=device)
+        self.recv = ([torch.zeros(self.max_own * 3, dtype=torch.float32, device=device) for _ in range(world)]
+                     if rank == 0 else None)
+
+    def bytes_per_step(self):
+        """bytes rank 0 receives per gather"""
+        return (self.world - 1) * self.max_own * 12
+
+    def gather(self, rgb_flat):
+        """rgb_flat: this rank's frame buffer as a flat float tensor of width*height*3; on rank 0 the pixels
+        of the other ranks are written into it"""
+        import torch.distributed as dist
+        if self.world == 1:
+            return
+        rgb3 = rgb_flat.view(-1, 3)
+        n = self.idx[self.rank].numel()
+        self.send[: n * 3] = rgb3.index_select(0, self.idx[self.rank]).reshape(-1)
+        dist.gather(self.send, self.recv, dst=0)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                m = self.idx[r].numel()
+                rgb3.index_copy_(0, self.idx[r], self.recv[r][: m * 3].view(-1, 3))

@@ -1,0 +1,216 @@
+"""Host logic behind the C-ABI (no GPU): library loads and exports every
+declared symbol, loader / BVH build / image IO, scene validation errors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MEDIA = "/root/reference/media"  # only present in the build container
+needs_media = pytest.mark.skipif(not os.path.isdir(MEDIA), reason="reference media not on this machine")
+
+
+def test_library_exports_every_declared_symbol(B):
+    header = open(os.path.join(ROOT, "include", "mipt.h")).read()
+    declared = set(re.findall(r"\b(mipt_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(B.SYMBOLS), declared ^ set(B.SYMBOLS)
+    lib = B.lib()
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert b"gfx950" in lib.mipt_version()
+
+
+def test_no_gpu_means_error_not_fallback(B, sf):
+    """on a machine without a GPU every compute entry point must fail loudly"""
+    import subprocess
+    if subprocess.run(["bash", "-c", "ls /dev/kfd"], capture_output=True).returncode == 0:
+        pytest.skip("a GPU is present")
+    scene = sf.product_scene_from_mesh_arrays(*sf.load_scene_arrays("cornellbox"))
+    with pytest.raises(B.MiptError):
+        B.Context(scene)
+
+
+def test_bvh_build_equals_oracle_build(B, ob, sf):
+    """the product's builder (iterative, in place) and the oracle's (recursive restatement of
+    cs488.h:1412-1595, 1649-1659, 1718-1728) give identical trees: boxes, links, leaf order"""
+    for name in ("cornellbox", "cube", "teapot-glass", "testObj", "bunny"):
+        arrays = sf.load_scene_arrays(name)
+        mesh = B.Mesh.from_arrays(*arrays)
+        bvh = B.BVH(mesh)
+        a = bvh.arrays()
+        o = sf.oracle_scene_from_mesh_arrays(*arrays)
+        b = o.export_bvh()
+        st = o.stats()
+        assert (bvh.num_nodes, bvh.num_leaves, bvh.depth, bvh.max_leaf_size) == (st["nodes"], st["leaves"], st["depth"], st["max_leaf"])
+        for k in ("node_min", "node_max"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (name, k)
+        for k in ("id_hit", "id_miss", "leaf_first", "leaf_count", "id_parent", "id_sibling", "tri_index"):
+            assert np.array_equal(a[k], b[k]), (name, k)
+        interior = a["leaf_count"] == 0
+        assert np.array_equal(a["id_left"][interior], b["id_left"][interior])
+        assert np.array_equal(a["id_right"][interior], b["id_right"][interior])
+        # preorder: idLeft == id + 1; threading points forward
+        ids = np.arange(bvh.num_nodes)
+        assert np.all(a["id_left"][interior] == ids[interior] + 1)
+        assert np.all((a["id_miss"] == 0) | (a["id_miss"] > ids))
+
+
+def test_bvh_degenerate_inputs(B):
+    # one triangle; identical triangles (all SAH costs tie); zero-area parent box (area 0 -> NaN costs -> leaf)
+    tri = np.array([0, 0, 0, 1, 0, 0, 0, 1, 0], np.float32)
+    nrm = np.array([0, 0, 1] * 3, np.float32)
+    for n in (1, 2, 7):
+        mesh = B.Mesh.from_arrays(np.tile(tri, n), np.tile(nrm, n))
+        bvh = B.BVH(mesh)
+        a = bvh.arrays()
+        assert bvh.num_leaves >= 1 and a["leaf_count"].sum() == n
+        assert sorted(a["tri_index"].tolist()) == list(range(n))
+    seg = np.array([0, 0, 0, 1, 0, 0, 2, 0, 0], np.float32)  # degenerate: all points on a line
+    bvh = B.BVH(B.Mesh.from_arrays(np.tile(seg, 5), np.tile(nrm, 5)))
+    assert bvh.arrays()["leaf_count"].sum() == 5
+
+
+def test_single_triangle_mesh(B):
+    m = B.Mesh.single_triangle()  # cs488.h:949-970
+    assert m.num_triangles == 1
+    assert np.allclose(m.positions(), [-0.5, -0.5, 0, 0.5, -0.5, 0, 0, 0.5, 0])
+    assert np.allclose(m.normals(), [0, 0, 1] * 3)
+    assert np.allclose(m.texcoords(), [0, 0, 0, 1, 1, 0])
+
+
+@needs_media
+def test_obj_loader_counts_and_material_typing(B):
+    """TriangleMesh::load (cs488.h:835-923): triangle counts and the typing rules C:849-868"""
+    expect = {"cornellbox": (36, [0, 0, 0, 3, 0]), "cornellbox-metal": (36, None), "cornellbox-glass": (36, None),
+              "bunny": (69451, [0]), "teapot-glass": (15704, [2]), "testObj": (11950, [0] * 5), "cube": (12, None),
+              "textured": (2, None)}
+    for name, (ntri, types) in expect.items():
+        m = B.Mesh.load(os.path.join(MEDIA, name + ".obj"))
+        assert m.num_triangles == ntri
+        if types is not None:
+            assert [x["type"] for x in m.materials()] == types
+    glass = B.Mesh.load(os.path.join(MEDIA, "teapot-glass.obj")).materials()[0]
+    assert glass["eta"] == 1.5 and glass["tex_id"] == 0  # name "glass*" -> eta 1.5; map_Kd default.png
+    metal = B.Mesh.load(os.path.join(MEDIA, "cornellbox-metal.obj")).materials()
+    assert 1 in [x["type"] for x in metal]  # Ns == 100 -> MAT_METAL
+    bunny = B.Mesh.load(os.path.join(MEDIA, "bunny.obj"))
+    assert abs(bunny.materials()[0]["Kd"][0] - 0.9) < 1e-7  # no mtl -> one default Lambertian
+    n = bunny.normals().reshape(-1, 3, 3)
+    assert np.array_equal(n[:, 0], n[:, 1]) and np.array_equal(n[:, 0], n[:, 2])  # face normals (C:884-892)
+
+
+@needs_media
+def test_committed_scene_fixtures_equal_the_loader(B, sf):
+    for name in ("cornellbox", "teapot-glass", "textured"):
+        m = B.Mesh.load(os.path.join(MEDIA, name + ".obj"))
+        pos, nrm, uv, mid, mats, texs = sf.load_scene_arrays(name)
+        assert np.array_equal(pos.view(np.uint32), m.positions().view(np.uint32))
+        assert np.array_equal(nrm.view(np.uint32), m.normals().view(np.uint32))
+        assert np.array_equal(uv.view(np.uint32), m.texcoords().view(np.uint32))
+        assert np.array_equal(mid, m.material_ids())
+        assert all(np.array_equal(a, b) for a, b in zip(texs, m.textures()))
+
+
+def test_loader_errors(B, tmp_path):
+    with pytest.raises(B.MiptError):
+        B.Mesh.load(str(tmp_path / "missing.obj"))
+    p = tmp_path / "empty.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\n")
+    with pytest.raises(B.MiptError):
+        B.Mesh.load(str(p))
+    p = tmp_path / "badidx.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(B.MiptError):
+        B.Mesh.load(str(p))
+    p = tmp_path / "nomtl.obj"
+    p.write_text("mtllib nothere.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    with pytest.raises(B.MiptError):
+        B.Mesh.load(str(p))
+
+
+def test_loader_small_obj_with_mtl(B, tmp_path):
+    (tmp_path / "m.mtl").write_text("newmtl lightA\nKd 1 1 1\nNs 5\nnewmtl mirror\nKs .9 .8 .7\nNs 100\nnewmtl glassy\nNs 1\n")
+    (tmp_path / "s.obj").write_text(
+        "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvn 0 0 2\nusemtl mirror\nf 1//1 2//1 3//1\nusemtl glassy\n"
+        "f 1//1 3//1 4//1 2//1\nusemtl lightA\nf 2//1 3//1 4//1\n")
+    m = B.Mesh.load(str(tmp_path / "s.obj"))
+    assert m.num_triangles == 3  # the quad contributes its first three vertices only (C:1177)
+    assert m.material_ids().tolist() == [1, 2, 0]
+    assert [x["type"] for x in m.materials()] == [B.MAT_LIGHT, B.MAT_METAL, B.MAT_GLASS]
+    assert np.allclose(m.normals()[:3], [0, 0, 1])  # vn normalised at parse time (C:1133-1137)
+    assert m.materials()[2]["Ks"] == pytest.approx((0.9, 0.8, 0.7))  # Ks carries over to the next material
+
+
+def test_image_hdr_png_roundtrip(B, sf, tmp_path):
+    env = sf.procedural_env(64)
+    p = str(tmp_path / "e.hdr")
+    B.save_hdr(p, env)
+    back = B.Image.load(p).pixels()
+    assert back.shape == env.shape
+    # RGBE keeps 8 mantissa bits of the largest channel
+    assert np.all(np.abs(back - env) <= env.max(axis=2, keepdims=True) / 128.0 + 1e-6)
+    # orientation: row 0 is the bottom row on both sides
+    assert np.argmax(back.sum(axis=(1, 2))) == np.argmax(env.sum(axis=(1, 2)))
+    png = str(tmp_path / "o.png")
+    ramp = np.zeros((4, 8, 3), np.float32)
+    ramp[..., 0] = np.linspace(-0.5, 1.5, 8)[None, :]  # clamp both ends (Image::save, C:223-236)
+    ramp[3, :, 1] = 1.0  # top row green
+    B.save_png(png, ramp)
+    img = B.Image.load(png).pixels()  # PNG -> float goes through pow(v/255, 2.2)
+    assert img.shape == (4, 8, 3)
+    assert np.all(img[3, :, 1] == 1.0) and np.all(img[:3, :, 1] == 0.0)
+    expect = np.power(np.floor(255.0 * np.clip(ramp[0, :, 0], 0, 1)) / 255.0, 2.2)
+    assert np.allclose(img[0, :, 0], expect, atol=1e-6)
+    B.save_pfm(str(tmp_path / "o.pfm"), ramp)
+    raw = open(tmp_path / "o.pfm", "rb").read()
+    assert raw.startswith(b"PF\n8 4\n-1.0\n") and len(raw) == len(b"PF\n8 4\n-1.0\n") + ramp.nbytes
+
+
+@needs_media
+def test_png_decoder_on_reference_textures(B):
+    teapot = B.Mesh.load(os.path.join(MEDIA, "teapot-glass.obj"))
+    tex = teapot.textures()[0]  # default.png: 128x128, 1-bit palette
+    assert tex.shape == (128, 128, 3) and len(np.unique(tex.reshape(-1, 3), axis=0)) <= 2
+    tex2 = B.Mesh.load(os.path.join(MEDIA, "textured.obj")).textures()[0]  # test.png: 1044x1059 RGB
+    assert tex2.shape == (1059, 1044, 3) and tex2.std() > 10
+
+
+def test_scene_validation_rejects_bad_links(B, sf):
+    """the device walk trusts the links; mipt_scene_create must refuse anything that could loop or overrun"""
+    arrays = sf.load_scene_arrays("cube")
+    mesh = B.Mesh.from_arrays(*arrays)
+    bvh = B.BVH(mesh)
+    lights = (B.Light * 1)()
+    good = B.SceneDesc()
+    B.check(B.lib().mipt_scene_desc_fill(mesh.h, bvh.h, None, lights, 1, C.byref(good)))
+    h = C.c_void_p()
+    B.check(B.lib().mipt_scene_create(C.byref(good), C.byref(h)))
+    B.lib().mipt_scene_destroy(h)
+    a = bvh.arrays()
+
+    def with_patch(field, arr):
+        d = B.SceneDesc()
+        C.pointer(d)[0] = good
+        keep = np.ascontiguousarray(arr)
+        setattr(d, field, keep.ctypes.data_as(type(getattr(d, field))))
+        out = C.c_void_p()
+        rc = B.lib().mipt_scene_create(C.byref(d), C.byref(out))
+        if rc == 0:
+            B.lib().mipt_scene_destroy(out)
+        return rc
+
+    bad = a["id_miss"].copy(); bad[3] = 1  # backward link -> possible cycle
+    assert with_patch("id_miss", bad) == -1
+    bad = a["id_hit"].copy(); bad[0] = 0  # interior node whose hit link is the sentinel
+    assert with_patch("id_hit", bad) == -1
+    bad = a["leaf_first"].copy(); bad[np.flatnonzero(a["leaf_count"])[0]] = 10 ** 6
+    assert with_patch("leaf_first", bad) == -1
+    bad = a["tri_index"].copy(); bad[0] = 999
+    assert with_patch("tri_index", bad) == -1
+    d = B.SceneDesc()
+    C.pointer(d)[0] = good
+    d.n_lights = 17
+    assert B.lib().mipt_scene_create(C.byref(d), C.byref(h)) == -5  # MIPT_ERR_LIMIT
+    assert b"16" in B.lib().mipt_last_error()
