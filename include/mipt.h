@@ -269,6 +269,11 @@ int mipt_buffer_zero(mipt_ctx* ctx, void* dev_ptr, size_t bytes);
 int mipt_buffer_upload(mipt_ctx* ctx, void* dev_ptr, const void* host_ptr, size_t bytes);
 int mipt_buffer_download(mipt_ctx* ctx, void* host_ptr, const void* dev_ptr, size_t bytes);
 
+/* Self-test (no counterpart in the reference): the traversal kernel replaces the six IEEE divisions of
+ * AABB::intersect (C:574-580) by a per-ray reciprocal plus residual correction that must round exactly like
+ * `/`; this runs that sequence against `/` on n_pairs operand pairs on the GPU and reports the mismatches (0). */
+int mipt_selftest_fast_division(mipt_ctx* ctx, uint64_t n_pairs, uint32_t seed, uint64_t* mismatches);
+
 int mipt_context_synchronize(mipt_ctx* ctx);
 /* profiling: HIP events around every kernel launch on the context's stream */
 int mipt_context_set_profiling(mipt_ctx* ctx, int enabled);

@@ -78,7 +78,7 @@ SYMBOLS = [
     "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_destroy",
     "mipt_context_create", "mipt_context_destroy", "mipt_context_arena_bytes",
     "mipt_trace", "mipt_trace_device", "mipt_occluded", "mipt_eye_rays", "mipt_background",
-    "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
+    "mipt_selftest_fast_division", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
     "mipt_render_device", "mipt_render", "mipt_context_synchronize", "mipt_context_set_profiling",
     "mipt_context_set_counting", "mipt_context_get_stats", "mipt_context_reset_stats",
 ]
@@ -145,6 +145,7 @@ def lib():
     L.mipt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp]
     L.mipt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), fp]
     L.mipt_context_synchronize.argtypes = [vp]
+    L.mipt_selftest_fast_division.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
     L.mipt_buffer_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mipt_buffer_free.argtypes = [vp, vp]
     L.mipt_buffer_zero.argtypes = [vp, vp, C.c_size_t]
@@ -466,6 +467,11 @@ class Context:
 
     def synchronize(self):
         check(lib().mipt_context_synchronize(self.h))
+
+    def selftest_fast_division(self, n_pairs, seed=1):
+        bad = C.c_uint64(0)
+        check(lib().mipt_selftest_fast_division(self.h, n_pairs, seed, C.byref(bad)))
+        return bad.value
 
     def buffer_alloc(self, nbytes, zero=True):
         p = C.c_void_p()

@@ -43,6 +43,7 @@ struct mipt_scene {
     std::vector<unsigned char> texels;
     std::vector<float> env;
     int nNodes = 0, nLeafTris = 0, nTris = 0, nMaterials = 0, envW = 0, envH = 0, nLights = 0;
+    bool planesTame = true;  // see DevScene::planesTame
 };
 
 struct DevBuf {
@@ -83,6 +84,7 @@ struct mipt_ctx {
     PathBuffers pb{};
     std::vector<int> tileKey;
     int nOwnedTiles = 0;
+    size_t pbPixels = 0;
     // stats
     bool profiling = false, counting = false;
     unsigned long long* dTotals = nullptr;  // [0] ext rays [1] shadow rays [2..3] closest visits/tests [4..5] occluded
@@ -131,15 +133,24 @@ void count_launch(mipt_ctx* c, int cls) {
     else c->acc.launches_other++;
 }
 
-void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, float4* hits) {
+// cursor == nullptr: use (and zero) the context's own cursor word
+void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, unsigned* cursor, float4* hits) {
+    if (!cursor) {
+        cursor = (unsigned*)(c->dTotals + 6);
+        (void)hipMemsetAsync(cursor, 0, 4, c->stream);
+    }
     Timer t(c, 0);
     count_launch(c, 0);
-    launch_trace_closest(c->stream, c->ds, rays, index, q, hits, c->counting ? c->dTotals + 2 : nullptr);
+    launch_trace_closest(c->stream, c->ds, rays, index, q, cursor, hits, c->counting ? c->dTotals + 2 : nullptr);
 }
-void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueView q, unsigned char* occ) {
+void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueView q, unsigned* cursor, unsigned char* occ) {
+    if (!cursor) {
+        cursor = (unsigned*)(c->dTotals + 7);
+        (void)hipMemsetAsync(cursor, 0, 4, c->stream);
+    }
     Timer t(c, 1);
     count_launch(c, 1);
-    launch_trace_occluded(c->stream, c->ds, rays, target, q, occ, c->counting ? c->dTotals + 4 : nullptr);
+    launch_trace_occluded(c->stream, c->ds, rays, target, q, cursor, occ, c->counting ? c->dTotals + 4 : nullptr);
 }
 QueueView dense(size_t n) { return QueueView{nullptr, 0u, (unsigned)n}; }
 
@@ -206,6 +217,13 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
             } else {
                 if (!(hit > i && hit < n)) { delete s; return fail(MIPT_ERR_INVALID, "an interior node's id_hit must point forward"); }
                 link = hit;
+            }
+            for (int a = 0; a < 3; a++) {
+                if (!(d->node_min[3 * i + a] <= d->node_max[3 * i + a])) s->planesTame = false;  // slab_hit_fast needs lo <= hi
+                for (const float v : {d->node_min[3 * i + a], d->node_max[3 * i + a]}) {
+                    const float m = std::fabs(v);
+                    if (!(v == 0.0f || (m >= 0x1p-40f && m <= 0x1p40f))) s->planesTame = false;  // also catches NaN / inf
+                }
             }
             s->nodes[(size_t)2 * i] = make_float4(d->node_min[3 * i], d->node_min[3 * i + 1], d->node_min[3 * i + 2],
                                                   __builtin_bit_cast(float, miss));
@@ -311,6 +329,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.lights = (const float4*)(base + oLights);
     c->ds.nNodes = s->nNodes; c->ds.nLeafTris = s->nLeafTris; c->ds.nTris = s->nTris; c->ds.nMaterials = s->nMaterials;
     c->ds.envW = s->envW; c->ds.envH = s->envH; c->ds.nLights = s->nLights;
+    c->ds.planesTame = s->planesTame ? 1 : 0;
     if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->dTotals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         mipt_context_destroy(c);
@@ -429,12 +448,27 @@ int mipt_context_reset_stats(mipt_ctx* c) {
     return MIPT_OK;
 }
 
+int mipt_selftest_fast_division(mipt_ctx* c, uint64_t n_pairs, uint32_t seed, uint64_t* mismatches) {
+    if (!c || !mismatches) return fail(MIPT_ERR_INVALID, "mipt_selftest_fast_division: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long* dBad = c->dTotals + 6;
+    HIP_TRY(hipMemsetAsync(dBad, 0, 8, c->stream));
+    const unsigned blocks = 4096, perThread = (unsigned)((n_pairs + (uint64_t)blocks * kBlock - 1) / ((uint64_t)blocks * kBlock));
+    launch_divcheck(c->stream, seed, blocks, perThread, dBad);
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, dBad, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    *mismatches = h;
+    return MIPT_OK;
+}
+
 int mipt_trace_device(mipt_ctx* c, const void* rays_dev, size_t n, void* hits_dev) {
     if (!c || (n && (!rays_dev || !hits_dev))) return fail(MIPT_ERR_INVALID, "mipt_trace_device: null argument");
     if (n > 0x7fffffffu) return fail(MIPT_ERR_LIMIT, "mipt_trace_device: at most 2^31-1 rays per call");
     if (n == 0) return MIPT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    trace_closest(c, (const float4*)rays_dev, nullptr, dense(n), (float4*)hits_dev);
+    trace_closest(c, (const float4*)rays_dev, nullptr, dense(n), nullptr, (float4*)hits_dev);
     c->acc.rays_closest += n;
     HIP_TRY(hipGetLastError());
     return MIPT_OK;
@@ -455,7 +489,7 @@ int mipt_trace(mipt_ctx* c, const float* ray_o, const float* ray_d, size_t n, fl
     if ((rc = c->sRays.ensure(rays.size() * sizeof(float4))) != MIPT_OK) return rc;
     if ((rc = c->sHits.ensure(n * sizeof(float4))) != MIPT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->sRays.p, rays.data(), rays.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    trace_closest(c, (const float4*)c->sRays.p, nullptr, dense(n), (float4*)c->sHits.p);
+    trace_closest(c, (const float4*)c->sRays.p, nullptr, dense(n), nullptr, (float4*)c->sHits.p);
     c->acc.rays_closest += n;
     std::vector<float4> hits(n);
     HIP_TRY(hipMemcpyAsync(hits.data(), c->sHits.p, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
@@ -496,7 +530,7 @@ int mipt_occluded(mipt_ctx* c, const float* ray_o, const float* ray_d, const flo
     if ((rc = c->sAux.ensure(n)) != MIPT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->sRays.p, rays.data(), rays.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->sAux.p, 0, n, c->stream));
-    trace_occluded(c, (const float4*)c->sRays.p, nullptr, dense(n), (unsigned char*)c->sAux.p);
+    trace_occluded(c, (const float4*)c->sRays.p, nullptr, dense(n), nullptr, (unsigned char*)c->sAux.p);
     c->acc.rays_occluded += n;
     HIP_TRY(hipMemcpyAsync(occluded, c->sAux.p, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -551,9 +585,10 @@ int mipt_background(mipt_ctx* c, const float* dir, size_t n, float* rgb) {
 }
 
 // carve the integrator's buffers out of one allocation
-static int ensure_path_buffers(mipt_ctx* c, size_t cap) {
+// cap = path slots (pixel slots x samples in flight); nPix = pixel slots (the metal chain of direct mode is per pixel)
+static int ensure_path_buffers(mipt_ctx* c, size_t cap, size_t nPix) {
     const int nl = c->ds.nLights > 0 ? c->ds.nLights : 1;
-    if (c->pb.capacity >= cap && c->pb.nLights == nl) return MIPT_OK;
+    if (c->pb.capacity >= cap && c->pb.nLights == nl && c->pbPixels >= nPix) return MIPT_OK;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
     const size_t f4 = sizeof(float4);
@@ -561,17 +596,20 @@ static int ensure_path_buffers(mipt_ctx* c, size_t cap) {
     const size_t regionSize = regionWaves * 64, space = regionSize * kShards;  // >= cap
     const size_t oRays = take(2 * cap * f4), oHit = take(cap * f4), oMult = take(cap * f4), oCnst = take(cap * f4);
     const size_t oPend = take(cap * f4), oHm = take(cap * f4), oVP = take(cap * f4), oVN = take(cap * f4), oVT = take(cap * f4);
-    const size_t oContrib = take(cap * nl * f4), oOcc = take(cap * nl), oKs = take(cap * 6 * f4), oPix = take(cap * 4);
+    const size_t oContrib = take(cap * nl * f4), oOcc = take(cap * nl), oKs = take(nPix * 6 * f4), oPix = take(cap * 4);
+    const size_t oRes = take(cap * f4);
     const size_t oQ0 = take(space * 4), oQ1 = take(space * 4), oQA = take(space * 4);
     const size_t oSh = take(2 * space * nl * f4), oShT = take(space * nl * 4), oCnt = take(kCounterWords * 4);
     int rc = c->pathMem.ensure(o);
-    if (rc != MIPT_OK) { c->pb.capacity = 0; return rc; }
+    if (rc != MIPT_OK) { c->pb.capacity = 0; c->pbPixels = 0; return rc; }
+    c->pbPixels = nPix;
     unsigned char* b = (unsigned char*)c->pathMem.p;
     PathBuffers& pb = c->pb;
     pb.capacity = cap; pb.nLights = nl; pb.regionSize = (unsigned)regionSize; pb.space = (unsigned)space;
     pb.rays = (float4*)(b + oRays); pb.hit = (float4*)(b + oHit); pb.mult = (float4*)(b + oMult); pb.cnst = (float4*)(b + oCnst);
     pb.pendL = (float4*)(b + oPend); pb.hitMul = (float4*)(b + oHm); pb.vP = (float4*)(b + oVP); pb.vN = (float4*)(b + oVN);
     pb.vTex = (float4*)(b + oVT); pb.contrib = (float4*)(b + oContrib); pb.occ = b + oOcc; pb.ksStack = (float4*)(b + oKs);
+    pb.res = (float4*)(b + oRes);
     pb.pixel = (int*)(b + oPix); pb.qExt[0] = (int*)(b + oQ0); pb.qExt[1] = (int*)(b + oQ1); pb.qAct = (int*)(b + oQA);
     pb.shRays = (float4*)(b + oSh); pb.shTarget = (int*)(b + oShT); pb.counters = (unsigned*)(b + oCnt);
     pb.visitCounters = c->dTotals + 2;
@@ -606,9 +644,17 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
         c->nOwnedTiles = (int)tiles.size();
     }
     if (c->nOwnedTiles == 0) return MIPT_OK;
-    const size_t cap = (size_t)c->nOwnedTiles * tileW * tileH;
-    if (cap > ((size_t)1 << 27)) return fail(MIPT_ERR_LIMIT, "more than 2^27 pixels in one partition");
-    if ((rc = ensure_path_buffers(c, cap)) != MIPT_OK) return rc;
+    const size_t nPix = (size_t)c->nOwnedTiles * tileW * tileH;  // pixel slots of this partition
+    if (nPix > ((size_t)1 << 25)) return fail(MIPT_ERR_LIMIT, "more than 2^25 pixels in one partition");
+    // path mode traces several samples of every pixel together: bigger queues keep the persistent traversal
+    // wavefronts fed (HBM is large: ~250 B per path slot, at most 2^25 slots = 8 GB)
+    int inFlight = 1;
+    if (rp->mode == MIPT_MODE_PATH) {
+        const size_t fit = ((size_t)1 << 25) / nPix;
+        inFlight = (int)(fit < 1 ? 1 : (fit > (size_t)rp->spp ? (size_t)rp->spp : fit));
+    }
+    const size_t cap = nPix * (size_t)inFlight;
+    if ((rc = ensure_path_buffers(c, cap, nPix)) != MIPT_OK) return rc;
     const PathBuffers& pb = c->pb;
     const int nl = pb.nLights;
 
@@ -616,6 +662,7 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
     fp.mode = rp->mode;
     fp.width = cam->width; fp.height = cam->height;
     fp.tileW = tileW; fp.tileH = tileH; fp.tilesX = tilesX; fp.nOwnedTiles = c->nOwnedTiles;
+    fp.nTilePaths = (unsigned)nPix;
     fp.tileList = (const int*)c->tileMem.p;
     fp.accum = accum_dev; fp.rgb = rgb_dev;
     fp.seedHash = pcg_hash_host(rp->seed);
@@ -630,9 +677,9 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
     }
     fp.lastIter = lastIter;
     const int nSamples = rp->mode == MIPT_MODE_PATH ? rp->spp : 1;
-    for (int sm = 0; sm < nSamples; sm++) {
-        fp.sample = (unsigned)(rp->sample_offset + sm);
-        fp.sampleCount = fp.sample + 1u;  // sampleCount++ before the loop, C:2232
+    for (int base = 0; base < nSamples; base += inFlight) {
+        fp.sample = (unsigned)(rp->sample_offset + base);
+        fp.samplesInFlight = (nSamples - base) < inFlight ? (nSamples - base) : inFlight;
         HIP_TRY(hipMemsetAsync(pb.counters, 0, kCounterWords * 4, c->stream));
         {
             Timer tm(c, 2);
@@ -642,7 +689,8 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
         int itDone = 0;
         for (int it = 0; it <= lastIter; it++) {
             trace_closest(c, pb.rays, pb.qExt[it & 1],
-                          QueueView{pb.counters + counter_index(it, 0, 0), pb.regionSize, pb.space}, pb.hit);
+                          QueueView{pb.counters + counter_index(it, 0, 0), pb.regionSize, pb.space},
+                          pb.counters + counter_index(it, 3, 0), pb.hit);
             {
                 Timer tm(c, 2);
                 count_launch(c, 2);
@@ -651,7 +699,8 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
             if (rp->mode != MIPT_MODE_PRIMARY) {
                 trace_occluded(c, pb.shRays, pb.shTarget,
                                QueueView{pb.counters + counter_index(it, 2, 0), pb.regionSize * (unsigned)nl,
-                                         pb.space * (unsigned)nl}, pb.occ);
+                                         pb.space * (unsigned)nl},
+                               pb.counters + counter_index(it, 4, 0), pb.occ);
                 Timer tm(c, 2);
                 count_launch(c, 2);
                 launch_shade_b(c->stream, c->ds, fp, pb, it);
@@ -667,6 +716,11 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
                 for (int sh = 0; sh < kShards; sh++) next += cnt[(size_t)sh * kCntStride];
                 if (next == 0) break;
             }
+        }
+        if (rp->mode == MIPT_MODE_PATH) {
+            Timer tm(c, 2);
+            count_launch(c, 2);
+            launch_resolve_samples(c->stream, fp, pb);
         }
         launch_fold_counters(c->stream, pb.counters, itDone, c->dTotals);
         c->acc.launches_other++;

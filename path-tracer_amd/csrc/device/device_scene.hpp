@@ -37,6 +37,7 @@ struct DevScene {
     const float* env;
     const float4* lights;
     int nNodes, nLeafTris, nTris, nMaterials, envW, envH, nLights;
+    int planesTame;  // every box plane is 0 or has magnitude in [2^-40, 2^40]: the exact fast slab division may be used
 };
 
 // ray record, 32 B: {o.xyz, tmin} {d.xyz, tmax}

@@ -21,7 +21,8 @@ constexpr int kMaxIter = 66;         // bounce iterations a frame can enqueue (c
 // overflow.  Slot i of a queue is live iff (i % regionSize) < count[i / regionSize].
 constexpr int kShards = 64;
 constexpr int kCntStride = 32;       // unsigned words between two shard counters (128 B)
-constexpr int kQueuesPerIter = 3;    // 0 = extension, 1 = waiting Lambertian vertices, 2 = shadow rays
+constexpr int kQueuesPerIter = 5;    // 0 = extension, 1 = waiting Lambertian vertices, 2 = shadow rays,
+                                     // 3 / 4 = work cursors of the closest-hit / any-hit launch (shard 0 only)
 
 __host__ __device__ inline size_t counter_index(int it, int queue, int shard) {
     return (((size_t)it * kQueuesPerIter + queue) * kShards + shard) * kCntStride;
@@ -55,6 +56,7 @@ struct PathBuffers {
     unsigned char* occ;   // [p*nLights+i] 1 = occluded
     float4* ksStack;      // [p*6+k] metal Ks chain (direct mode)
     int* pixel;           // pixel index of the path, -1 = outside the image
+    float4* res;          // {radiance of the finished path, bits(RES_*)}: resolved into accum/rgb in sample order
     int* qExt[2];         // ping-pong queues of path slots to extend
     int* qAct;            // Lambertian vertices waiting for their shadow rays
     float4* shRays;       // shadow-ray queue, 2 float4 per ray
@@ -65,7 +67,9 @@ struct PathBuffers {
 
 struct FrameParams {
     int mode, level, maxBounces, lastIter;
-    unsigned seedHash, sample, sampleCount;
+    unsigned seedHash, sample;      // sample = index of the first sample in flight
+    int samplesInFlight;            // path mode: samples of every pixel traced together (1 otherwise)
+    unsigned nTilePaths;            // path slots per sample = owned tiles x tile pixels
     int width, height;
     int tileW, tileH, tilesX, nOwnedTiles;
     const int* tileList;  // owned tile ids
@@ -73,20 +77,24 @@ struct FrameParams {
     float* rgb;
 };
 
+// cursor: one zeroed word per launch (the work counter the persistent wavefronts pull ray chunks from)
 void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
-                          float4* hits, unsigned long long* counters);
+                          unsigned* cursor, float4* hits, unsigned long long* counters);
 void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
-                           unsigned char* occ, unsigned long long* counters);
+                           unsigned* cursor, unsigned char* occ, unsigned long long* counters);
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays);
 void launch_resolve_hits(hipStream_t st, const DevScene& s, const float4* rays, const float4* hits, size_t n,
                          float* out);
 void launch_background(hipStream_t st, const DevScene& s, const float* dir, size_t n, float* rgb);
+
+void launch_divcheck(hipStream_t st, unsigned seed, unsigned blocks, unsigned perThread, unsigned long long* mismatches);
 
 // integrator (kernels_integrate.hip)
 void launch_generate(hipStream_t st, const CameraDev& cam, const FrameParams& fp, const PathBuffers& pb);
 void launch_shade_a(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter);
 void launch_shade_b(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter);
 // totals[0] += sum of extension-queue lengths, totals[1] += sum of shadow-queue lengths over iterations [0, nIter)
+void launch_resolve_samples(hipStream_t st, const FrameParams& fp, const PathBuffers& pb);
 void launch_fold_counters(hipStream_t st, const unsigned* counters, int nIter, unsigned long long* totals);
 
 }  // namespace ptd

@@ -49,14 +49,12 @@ __device__ __forceinline__ bool slot_live(const unsigned* shard0, unsigned regio
 __device__ __forceinline__ vec3 xyz(const float4 v) { return vec3{v.x, v.y, v.z}; }
 __device__ __forceinline__ float4 pack(const vec3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 
-// AccumulationBuffer += result; FrameBuffer = Accum / sampleCount  (C:2240-2241)
-__device__ __forceinline__ void finish_path(const FrameParams& fp, int pix, const vec3 result) {
-    float* a = fp.accum + (size_t)3 * pix;
-    float* q = fp.rgb + (size_t)3 * pix;
-    const float ax = a[0] + result.x, ay = a[1] + result.y, az = a[2] + result.z;
-    a[0] = ax; a[1] = ay; a[2] = az;
-    const float sc = (float)fp.sampleCount;
-    q[0] = ax / sc; q[1] = ay / sc; q[2] = az / sc;
+// Path mode keeps several samples of every pixel in flight (slot p = sample * nTilePaths + pixel slot), so a
+// finished path only RECORDS its radiance; k_resolve_samples adds the records to the AccumulationBuffer in sample
+// order afterwards, which keeps the float sums identical to the reference's sample-after-sample loop (C:2240-2241).
+enum : int { RES_NONE = 0, RES_ACCUMULATE = 1, RES_BACKGROUND = 2 };
+__device__ __forceinline__ void finish_path(const PathBuffers& pb, unsigned p, const vec3 result) {
+    pb.res[p] = make_float4(result.x, result.y, result.z, i2f(RES_ACCUMULATE));
 }
 __device__ __forceinline__ void write_pixel(const FrameParams& fp, int pix, const vec3 v) {
     float* q = fp.rgb + (size_t)3 * pix;
@@ -66,12 +64,13 @@ __device__ __forceinline__ void write_pixel(const FrameParams& fp, int pix, cons
 // ---- generate: eye rays for this context's tiles (C:2183-2197) ----
 __global__ __launch_bounds__(kBlock) void k_generate(CameraDev cam, FrameParams fp, PathBuffers pb) {
     const unsigned tilePix = (unsigned)(fp.tileW * fp.tileH);
-    const unsigned n = (unsigned)fp.nOwnedTiles * tilePix;
+    const unsigned n = fp.nTilePaths * (unsigned)fp.samplesInFlight;
     for (unsigned p = blockIdx.x * kBlock + threadIdx.x; p < pb.space; p += gridDim.x * kBlock) {
         bool valid = p < n;
         int pix = -1;
         if (valid) {
-            const unsigned k = p / tilePix, r = p % tilePix;
+            const unsigned j = p % fp.nTilePaths;  // pixel slot; p / nTilePaths is the sample in flight
+            const unsigned k = j / tilePix, r = j % tilePix;
             const unsigned blk = r >> 6, lane = r & 63u;  // 8x8 pixel block per wavefront
             const unsigned bpr = (unsigned)fp.tileW >> 3;
             const int lx = (int)((blk % bpr) * 8u + (lane & 7u));
@@ -88,9 +87,35 @@ __global__ __launch_bounds__(kBlock) void k_generate(CameraDev cam, FrameParams 
                 pb.rays[2 * (size_t)p + 1] = pack(d, kFltMax);
             }
             pb.pixel[p] = pix;
+            pb.res[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(RES_NONE));
         }
         const unsigned slot = wave_append(pb.counters + counter_index(0, 0, 0), pb.regionSize, (p >> 6) % (unsigned)kShards, valid);
         if (valid) pb.qExt[0][slot] = (int)p;
+    }
+}
+
+// AccumulationBuffer += result; FrameBuffer = Accum / sampleCount, sample after sample (C:2232, C:2240-2244)
+__global__ __launch_bounds__(kBlock) void k_resolve_samples(FrameParams fp, PathBuffers pb) {
+    for (unsigned j = blockIdx.x * kBlock + threadIdx.x; j < fp.nTilePaths; j += gridDim.x * kBlock) {
+        const int pix = pb.pixel[j];
+        if (pix < 0) continue;
+        float* a = fp.accum + (size_t)3 * pix;
+        float* q = fp.rgb + (size_t)3 * pix;
+        float ax = a[0], ay = a[1], az = a[2];
+        bool touched = false;
+        for (int sm = 0; sm < fp.samplesInFlight; sm++) {
+            const float4 r = pb.res[(size_t)sm * fp.nTilePaths + j];
+            const int kind = f2i(r.w);
+            if (kind == RES_ACCUMULATE) {
+                ax += r.x; ay += r.y; az += r.z;
+                const float sc = (float)(fp.sample + (unsigned)sm + 1u);  // sampleCount++ precedes the sample's loop
+                q[0] = ax / sc; q[1] = ay / sc; q[2] = az / sc;
+                touched = true;
+            } else if (kind == RES_BACKGROUND) {
+                q[0] = r.x; q[1] = r.y; q[2] = r.z;
+            }
+        }
+        if (touched) { a[0] = ax; a[1] = ay; a[2] = az; }
     }
 }
 
@@ -130,7 +155,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
             bool alive = true;
             if (it == 0) {
                 if (tri < 0) {  // C:2244: miss pixels show the background, unaccumulated
-                    write_pixel(fp, pix, get_background(s, -d));
+                    const vec3 bg = get_background(s, -d);
+                    pb.res[p] = make_float4(bg.x, bg.y, bg.z, i2f(RES_BACKGROUND));
                     alive = false;
                 } else {
                     pb.hitMul[p] = make_float4(1.0f, 1.0f, 1.0f, i2f(0));  // rng dimension 0
@@ -142,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
                 const int missMode = f2i(l4.w);
                 if (tri < 0) {
                     const vec3 result = (missMode == MISS_LAMBERT) ? cnst + mult * L : cnst + mult * get_background(s, d);
-                    finish_path(fp, pix, result);
+                    finish_path(pb, p, result);
                     alive = false;
                 } else {
                     if (missMode == MISS_LAMBERT) cnst = cnst + L * mult;  // C:2322
@@ -185,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
                     toAct = true;
                 } else if (m.type == MIPT_MAT_METAL) {
                     if (capped) {
-                        finish_path(fp, pix, cnst);
+                        finish_path(pb, p, cnst);
                     } else {
                         const vec3 smp = mirror(-currDir, N);  // C:496
                         emit_extension(pb, p, P, 0.001f, smp);
@@ -198,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
                     }
                 } else if (m.type == MIPT_MAT_GLASS) {
                     if (capped) {
-                        finish_path(fp, pix, cnst);
+                        finish_path(pb, p, cnst);
                     } else {
                         const float eta2 = (m.eta == eta) ? 1.0f : m.eta;  // C:2359
                         const vec3 w = -currDir;
@@ -219,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
                         toExt = true;
                     }
                 } else {
-                    finish_path(fp, pix, vec3{0.0f, 0.0f, 0.0f});  // C:2391-2394, constTerm is dropped
+                    finish_path(pb, p, vec3{0.0f, 0.0f, 0.0f});  // C:2391-2394, constTerm is dropped
                 }
             }
         }
@@ -254,18 +280,19 @@ __global__ __launch_bounds__(kBlock) void k_shade_b_path(DevScene s, FrameParams
             }
             const float4 hm = pb.hitMul[p];
             unsigned dim = (unsigned)f2i(hm.w);
+            const unsigned sample = fp.sample + p / fp.nTilePaths;
             bool done = capped;
             if (!done && it > 5) {  // C:2311-2314, no weight compensation
-                if (counter_rand(fp.seedHash, (unsigned)pix, fp.sample, dim++) < .25f) done = true;
+                if (counter_rand(fp.seedHash, (unsigned)pix, sample, dim++) < .25f) done = true;
             }
             if (done) {
-                finish_path(fp, pix, cnst + mult * L);
+                finish_path(pb, p, cnst + mult * L);
             } else {
                 const float4 p4 = pb.vP[p];
                 const vec3 P = xyz(p4), N = xyz(pb.vN[p]), texture = xyz(pb.vTex[p]);
                 const MaterialDev m = load_material(s, f2i(p4.w));
-                const float u1 = counter_rand(fp.seedHash, (unsigned)pix, fp.sample, dim++);
-                const float u2 = counter_rand(fp.seedHash, (unsigned)pix, fp.sample, dim++);
+                const float u1 = counter_rand(fp.seedHash, (unsigned)pix, sample, dim++);
+                const float u2 = counter_rand(fp.seedHash, (unsigned)pix, sample, dim++);
                 const vec3 smp = sample_lambert(N, u1, u2);
                 const vec3 sample_brdf = m.Kd / kPI;
                 const float pdf = 1.0f / kPI;
@@ -451,6 +478,9 @@ void launch_shade_b(hipStream_t st, const DevScene& s, const FrameParams& fp, co
     else hipLaunchKernelGGL(k_shade_b_direct, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
 }
 
+void launch_resolve_samples(hipStream_t st, const FrameParams& fp, const PathBuffers& pb) {
+    hipLaunchKernelGGL(k_resolve_samples, dim3(grid_for(fp.nTilePaths)), dim3(kBlock), 0, st, fp, pb);
+}
 void launch_fold_counters(hipStream_t st, const unsigned* counters, int nIter, unsigned long long* totals) {
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, st, counters, nIter, totals);
 }

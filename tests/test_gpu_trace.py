@@ -125,3 +125,11 @@ def test_full_size_properties(B, ob, sf, name, w, h):
     # idempotence: tracing the same rays again gives the same bits
     tri2, t2, _ = ctx.trace(o, d)
     assert np.array_equal(tri, tri2) and np.array_equal(bits(t), bits(t2))
+
+
+def test_fast_division_is_ieee(B, sf):
+    """the slab test's reciprocal + residual-correction division (traverse.hpp: div_by_recip) rounds exactly like
+    IEEE `/` on 2^33 operand pairs inside its precondition range, incl. all-ones / single-bit mantissas and a = 0"""
+    scene, ctx, orc = setup_scene(B, sf, "cube")
+    for seed in (1, 2):
+        assert ctx.selftest_fast_division(1 << 32, seed) == 0

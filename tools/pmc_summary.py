@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Summarises gpurun_out/pmc_<tag>/ (tools/pmc_passes.sh) per kernel: prints a table and writes
+profiles/<round>/pmc_<tag>.json; with --traffic also writes profiles/traffic.json (HBM bytes per launch of the two
+traversal kernels, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE) for bench.py."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}", "*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].split("::")[-1]
+        if "k_trace" in name:
+            name = ("k_trace_occluded" if "k_trace<true" in name else "k_trace_closest") + ("_count" if ", true>" in name else "")
+        agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
+        calls[name][r["Counter_Name"]] += 1
+out = {}
+for k in sorted(agg):
+    v, n = agg[k], calls[k]
+    d = {c: v[c] for c in v}
+    d["launches"] = max(n.values())
+    if v.get("SQ_ACTIVE_INST_VALU"):
+        d["lanes_per_valu_inst"] = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_ACTIVE_INST_VALU"]
+        d["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / max(v["SQ_WAVES"], 1)
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+            d["frac_" + c] = v[c] / max(v["SQ_WAVE_CYCLES"], 1)
+    if v.get("TCC_HIT_sum") is not None and (v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0)) > 0:
+        d["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    if v.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        d["l1_hit_rate_est"] = 1.0 - v.get("TCP_TCC_READ_REQ_sum", 0) / v["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    if "FETCH_SIZE" in v:
+        # rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; gfx950 FETCH_SIZE counts 128-B requests at 64 B: doubled
+        d["hbm_read_bytes_per_launch"] = 2.0 * v["FETCH_SIZE"] * 1024.0 / n["FETCH_SIZE"]
+    if "WRITE_SIZE" in v:
+        d["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024.0 / n["WRITE_SIZE"]
+    out[k] = d
+os.makedirs(os.path.join(root, "profiles", rnd), exist_ok=True)
+json.dump(out, open(os.path.join(root, "profiles", rnd, f"pmc_{tag}.json"), "w"), indent=1, sort_keys=True)
+for k, d in out.items():
+    if not k.startswith("k_"):
+        continue
+    print(k, d["launches"])
+    for c in ("lanes_per_valu_inst", "valu_insts_per_wave", "frac_SQ_WAIT_ANY", "frac_SQ_WAIT_INST_ANY", "frac_SQ_ACTIVE_INST_VALU",
+              "l2_hit_rate", "l1_hit_rate_est", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "SQ_INSTS_VMEM_RD",
+              "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "TA_BUSY_avr", "SQ_WAVES"):
+        if c in d:
+            print(f"    {c}: {d[c]:.4g}")
+if "--traffic" in sys.argv:
+    t = {}
+    for k in ("k_trace_closest", "k_trace_occluded"):
+        if k in out and "hbm_read_bytes_per_launch" in out[k]:
+            t[k] = {"hbm_bytes_per_launch": out[k]["hbm_read_bytes_per_launch"] + out[k].get("hbm_write_bytes_per_launch", 0.0),
+                    "source": f"profiles/{rnd}/pmc_{tag}.json: 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes of "
+                              "bench.py --steps 2 --warmup 1, averaged over that kernel's launches"}
+    json.dump(t, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
