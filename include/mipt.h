@@ -217,6 +217,11 @@ int mipt_scene_desc_fill(const mipt_mesh* mesh, const mipt_bvh* bvh, const mipt_
 /* Validates and COPIES the description (caller may free its arrays at once). */
 int mipt_scene_create(const mipt_scene_desc* desc, mipt_scene** out);
 void mipt_scene_destroy(mipt_scene*);
+/* 1 when every box plane of the scene is 0 or of magnitude in [2^-61, 2^40] (and min <= max), so the traversal
+ * kernel may replace the six IEEE divisions of AABB::intersect (C:574-580) by its exact per-ray reciprocal
+ * sequence; 0: every ray of this scene takes the literal IEEE-division slab test.  Results are bit-identical
+ * either way; only the speed differs.  No counterpart in the reference. */
+int mipt_scene_exact_reciprocal(const mipt_scene*);
 
 /* One context per GPU: uploads the scene as ONE hipMalloc'd arena of flat
  * SoA sections (replaces create(&deviceScene, globalScene), G:3181).  A

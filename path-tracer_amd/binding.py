@@ -75,7 +75,7 @@ SYMBOLS = [
     "mipt_bvh_node_min", "mipt_bvh_node_max", "mipt_bvh_id_hit", "mipt_bvh_id_miss", "mipt_bvh_leaf_first",
     "mipt_bvh_leaf_count", "mipt_bvh_id_left", "mipt_bvh_id_right", "mipt_bvh_id_parent", "mipt_bvh_id_sibling",
     "mipt_bvh_tri_index", "mipt_bvh_destroy",
-    "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_destroy",
+    "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_destroy", "mipt_scene_exact_reciprocal",
     "mipt_context_create", "mipt_context_destroy", "mipt_context_arena_bytes",
     "mipt_trace", "mipt_trace_device", "mipt_occluded", "mipt_eye_rays", "mipt_background",
     "mipt_selftest_fast_division", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
@@ -132,6 +132,8 @@ def lib():
     for n in ("mipt_image_save_png", "mipt_image_save_hdr", "mipt_image_save_pfm"):
         getattr(L, n).argtypes = [C.c_char_p, C.c_int32, C.c_int32, fp]
     L.mipt_bvh_build.argtypes = [vp, C.POINTER(vp)]
+    L.mipt_scene_exact_reciprocal.argtypes = [vp]
+    L.mipt_scene_exact_reciprocal.restype = C.c_int32
     L.mipt_scene_desc_fill.argtypes = [vp, vp, vp, C.POINTER(Light), C.c_int32, C.POINTER(SceneDesc)]
     L.mipt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
     L.mipt_context_create.argtypes = [vp, C.c_int, vp, C.POINTER(vp)]
@@ -398,6 +400,11 @@ class Scene:
         h = C.c_void_p()
         check(lib().mipt_scene_create(C.byref(self.desc), C.byref(h)))
         self.h = h
+
+    @property
+    def exact_reciprocal(self):
+        """True when the scene's box planes allow the traversal kernel's exact reciprocal slab division"""
+        return bool(lib().mipt_scene_exact_reciprocal(self.h))
 
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:

@@ -7,6 +7,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,7 @@ struct mipt_scene {
     std::vector<float> env;
     int nNodes = 0, nLeafTris = 0, nTris = 0, nMaterials = 0, envW = 0, envH = 0, nLights = 0;
     bool planesTame = true;  // see DevScene::planesTame
+    int nTopNodes = 0;       // see DevScene::nTopNodes
 };
 
 struct DevBuf {
@@ -191,6 +193,42 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         // (or to 0 = done); enforcing that here guarantees that every walk on
         // the GPU terminates, whatever the caller passed in.
         s->nodes.resize((size_t)2 * n);
+        // Node numbering on the device: the kTopNodes nodes most likely to be visited come first, so that the
+        // traversal kernel can keep them in LDS (kernels_trace.hip).  Chosen greedily from the root by box surface
+        // area (the SAH's hit probability), children entering when their parent is taken, which keeps the set a
+        // connected top of the tree; then numbered in the original (preorder) order.  Only the numbering changes:
+        // every walk follows the same links, so visit order and results are untouched.
+        std::vector<int> perm((size_t)n);
+        {
+            auto area = [&](int i) -> float {
+                const float ex = d->node_max[3 * i] - d->node_min[3 * i], ey = d->node_max[3 * i + 1] - d->node_min[3 * i + 1],
+                            ez = d->node_max[3 * i + 2] - d->node_min[3 * i + 2];
+                const float a = 2.0f * (ex * ey + ey * ez + ez * ex);
+                return a == a ? a : 0.0f;
+            };
+            std::vector<char> top((size_t)n, 0);
+            std::priority_queue<std::pair<float, int>> pq;
+            pq.push({area(0), 0});
+            int nTop = 0;
+            while (!pq.empty() && nTop < ptd::kTopNodes) {
+                const int i = pq.top().second;
+                pq.pop();
+                if (top[i]) continue;
+                top[i] = 1;
+                nTop++;
+                if (d->leaf_count[i] > 0) continue;
+                const int l = d->id_hit[i];  // left child; the right one is where the left subtree's walk exits
+                if (l > i && l < n) {
+                    if (!top[l]) pq.push({area(l), l});
+                    const int r = d->id_miss[l];
+                    if (r > l && r < n && !top[r]) pq.push({area(r), r});
+                }
+            }
+            s->nTopNodes = nTop;
+            int next = 0;
+            for (int i = 0; i < n; i++) if (top[i]) perm[i] = next++;
+            for (int i = 0; i < n; i++) if (!top[i]) perm[i] = next++;
+        }
         s->leafTris.resize((size_t)3 * d->n_tri_index);
         std::vector<char> covered((size_t)d->n_tri_index, 0);
         for (int i = 0; i < n; i++) {
@@ -216,19 +254,19 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
                 }
             } else {
                 if (!(hit > i && hit < n)) { delete s; return fail(MIPT_ERR_INVALID, "an interior node's id_hit must point forward"); }
-                link = hit;
+                link = perm[hit];
             }
             for (int a = 0; a < 3; a++) {
                 if (!(d->node_min[3 * i + a] <= d->node_max[3 * i + a])) s->planesTame = false;  // slab_hit_fast needs lo <= hi
                 for (const float v : {d->node_min[3 * i + a], d->node_max[3 * i + a]}) {
                     const float m = std::fabs(v);
-                    if (!(v == 0.0f || (m >= 0x1p-40f && m <= 0x1p40f))) s->planesTame = false;  // also catches NaN / inf
+                    if (!(v == 0.0f || (m >= std::ldexp(1.0f, ptd::kTameLo) && m <= std::ldexp(1.0f, ptd::kTameHi)))) s->planesTame = false;  // also catches NaN / inf
                 }
             }
-            s->nodes[(size_t)2 * i] = make_float4(d->node_min[3 * i], d->node_min[3 * i + 1], d->node_min[3 * i + 2],
-                                                  __builtin_bit_cast(float, miss));
-            s->nodes[(size_t)2 * i + 1] = make_float4(d->node_max[3 * i], d->node_max[3 * i + 1], d->node_max[3 * i + 2],
-                                                      __builtin_bit_cast(float, link));
+            const size_t slot = (size_t)perm[i];
+            s->nodes[2 * slot] = make_float4(d->node_min[3 * i], d->node_max[3 * i], d->node_min[3 * i + 1], d->node_max[3 * i + 1]);
+            s->nodes[2 * slot + 1] = make_float4(d->node_min[3 * i + 2], d->node_max[3 * i + 2],
+                                                 __builtin_bit_cast(float, perm[miss]), __builtin_bit_cast(float, link));
         }
         for (char cv : covered)
             if (!cv) { delete s; return fail(MIPT_ERR_INVALID, "tri_index entry not owned by any leaf"); }
@@ -281,6 +319,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
 }
 
 void mipt_scene_destroy(mipt_scene* s) { delete s; }
+int mipt_scene_exact_reciprocal(const mipt_scene* s) { return (s && s->planesTame) ? 1 : 0; }
 
 int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx** out) {
     if (!s || !out) return fail(MIPT_ERR_INVALID, "mipt_context_create: null argument");
@@ -330,6 +369,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.nNodes = s->nNodes; c->ds.nLeafTris = s->nLeafTris; c->ds.nTris = s->nTris; c->ds.nMaterials = s->nMaterials;
     c->ds.envW = s->envW; c->ds.envH = s->envH; c->ds.nLights = s->nLights;
     c->ds.planesTame = s->planesTame ? 1 : 0;
+    c->ds.nTopNodes = s->nTopNodes;
     if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->dTotals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         mipt_context_destroy(c);

@@ -1,12 +1,15 @@
 // device_scene.hpp -- layout of the scene arena in HBM and the records the
 // kernels exchange.  One hipMalloc holds every section (256-B aligned):
 //
-//   nodes     2 x float4 per BVH node (32 B):
-//               lo = {min.xyz, bits(idMiss)}
-//               hi = {max.xyz, bits(link)}   link > 0: idHit of an interior node
+//   nodes     2 x float4 per BVH node (32 B), the two planes of an axis adjacent (packed fp32 math):
+//               n0 = {min.x, max.x, min.y, max.y}
+//               n1 = {min.z, max.z, bits(idMiss), bits(link)}
+//                                            link > 0: idHit of an interior node
 //                                            link < 0: leaf, first leaf triangle = ~link,
 //                                                      and its idHit == idMiss
 //             (threaded links of StacklessBVH, reference cs488.h:1637-1659; 0 = done)
+//             Device numbering: the root is 0, the kTopNodes nodes with the largest boxes (a connected
+//             top of the tree) come first, the rest follow in preorder; the links are renumbered to match.
 //   leafTris  3 x float4 per triangle reference (48 B), in leaf (triList) order:
 //               {p0.xyz, bits(original triangle id)}
 //               {p0-p1,  bits(1 if last triangle of its leaf)}
@@ -37,12 +40,15 @@ struct DevScene {
     const float* env;
     const float4* lights;
     int nNodes, nLeafTris, nTris, nMaterials, envW, envH, nLights;
-    int planesTame;  // every box plane is 0 or has magnitude in [2^-40, 2^40]: the exact fast slab division may be used
+    int nTopNodes;   // nodes [0, nTopNodes) are the top of the tree, numbered first so that k_trace can hold them in LDS
+    int planesTame;  // every box plane is 0 or has magnitude in [2^-61, 2^40] and min <= max: the exact reciprocal slab division may be used (traverse.hpp)
 };
 
 // ray record, 32 B: {o.xyz, tmin} {d.xyz, tmax}
 // hit record, 16 B: {bits(tri_id or -1), t, beta, gamma}
 
 constexpr int kBlock = 256;
+constexpr int kTraceBlock = 768;  // k_trace: 12 wavefronts per block, two blocks per CU (LDS: 2 x ~64 KB of 160 KB)
+constexpr int kTopNodes = 2032;   // nodes k_trace keeps in LDS (32 B each; with the shard prefix sums just under 64 KB)
 
 }  // namespace ptd

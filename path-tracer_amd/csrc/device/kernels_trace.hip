@@ -2,8 +2,8 @@
 // "occluded") and the small kernels around the parity entry points: eye-ray
 // generation, HitInfo resolution, environment lookup.
 //
-// Launch shape: 256-thread blocks (4 wavefronts of 64 lanes), one ray per
-// lane at a time.  Queue lengths live in device memory (sharded counters), so
+// Launch shape: k_trace runs 768-thread blocks (12 wavefronts of 64 lanes), two
+// per CU, one ray per lane at a time; the small kernels use 256-thread blocks.  Queue lengths live in device memory (sharded counters), so
 // a whole frame is enqueued without host syncs.
 #include "kernels.hpp"
 #include "shading.hpp"
@@ -22,9 +22,14 @@ namespace ptd {
 // active per VALU instruction -- profiles/r01):
 //   * persistent wavefronts with lane refill: a lane whose ray is finished
 //     takes the next ray of the queue (chunks of 64 indices per atomic);
-//   * a lane that reaches a leaf parks there; the wavefront votes per step
-//     between "box step" (lanes at a node) and "triangle step" (parked lanes),
-//     so both code paths run with many lanes instead of interleaving;
+//   * a lane that reaches a leaf parks the leaf (a 4-deep FIFO) and walks on;
+//     the wavefront runs "triangle steps" only when many lanes hold parked
+//     leaves, so both code paths run with many lanes instead of interleaving;
+//   * the top of the tree (DevScene::nTopNodes nodes, numbered first) is read
+//     from LDS: a wavefront's node loads are 64 different cache lines, which
+//     the CU's L1 takes one per cycle -- that, not HBM or the VALU, bounded the
+//     kernel (profiles/r01/pmc_v5.json: TA busy 0.75) -- and about half of all
+//     node visits fall into the top 2032 nodes;
 //   * the six slab quotients use a per-ray reciprocal with a residual
 //     correction that reproduces IEEE division exactly (traverse.hpp).
 // Queue: dense (q.counts == nullptr, q.space rays) or sharded (kernels.hpp);
@@ -32,17 +37,23 @@ namespace ptd {
 // a dense index.  index (nullable): queue slot -> ray slot; the result goes to
 // hits[ray slot] (closest hit) or occ[target[queue slot]] (any hit).
 constexpr int kRefillLanes = 16;  // refill when this many lanes are empty
-constexpr int kLeafLanes = 12;    // triangle step when this many lanes are parked at a leaf
-constexpr int kBoxBurst = 4;      // box steps between two votes
+constexpr int kLeafLanes = 40;      // start testing triangles when this many lanes hold parked leaves ...
+constexpr int kLeafLanesKeep = 16;  // ... and keep going while this many still do
+constexpr int kBoxBurst = 4;        // box steps between two votes
+constexpr int kPendClosest = 4;     // leaves a lane may park before it must wait (closest hit)
+constexpr int kPendAnyHit = 1;      // any-hit rays end at their first accepted triangle: parking more only wastes box steps
 
 template <bool ANYHIT, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const float4* __restrict__ rays,
+__global__ __launch_bounds__(kTraceBlock) void k_trace(DevScene s, const float4* __restrict__ rays,
                                                   const int* __restrict__ index, const int* __restrict__ target,
                                                   QueueView q, unsigned* __restrict__ cursor,
                                                   float4* __restrict__ hits, unsigned char* __restrict__ occ,
                                                   unsigned long long* __restrict__ counters) {
+    __shared__ float4 top[2 * kTopNodes];
     __shared__ unsigned prefix[kShards + 1];
     const int lane = threadIdx.x & 63;
+    const int nTop = s.nTopNodes;
+    for (int i = threadIdx.x; i < 2 * nTop; i += kTraceBlock) top[i] = s.nodes[i];
     if (q.counts) {
         if (threadIdx.x < 64) {
             unsigned v = q.counts[(size_t)lane * kCntStride];
@@ -53,16 +64,26 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const float4* __re
             prefix[lane + 1] = v;
             if (lane == 0) prefix[0] = 0;
         }
-        __syncthreads();
     }
+    __syncthreads();
     const unsigned total = q.counts ? prefix[kShards] : q.space;
+    // explicit address spaces: with two generic pointers the compiler merges the two arms of "LDS or global" into one
+    // flat load through a selected pointer, which sends the LDS lanes through the vector-memory path as well
+    const __attribute__((address_space(3))) float4v* topLds = (const __attribute__((address_space(3))) float4v*)top;
+    const __attribute__((address_space(1))) float4v* nodesGlobal = (const __attribute__((address_space(1))) float4v*)s.nodes;
 
     // lane state
-    enum { EMPTY = 0, SEARCH = 1, LEAF = 2 };
-    int state = EMPTY;
-    int node = 0, k = 0, cont = 0;
+    bool hasRay = false;
+    int node = 0;                     // next node to test; 0 after the walk has run off the tree (root is tested first)
+    bool walking = false;             // the box walk of this ray is still going
+    // FIFO of leaves whose triangles are still to be tested, in visit order.  cur = next triangle of the oldest
+    // parked leaf (-1: none); p0..p2 = first triangles of the nPend younger ones, newest in p0.  The walk does
+    // not depend on triangle results (the reference's box test ignores the current best hit, cs488.h:1669), so
+    // parking the triangle tests changes nothing but the schedule; the tests themselves run per lane in visit
+    // order, which keeps the strict-'<' tie-break.
+    int cur = -1, nPend = 0, p0 = 0, p1 = 0, p2 = 0;
     unsigned raySlot = 0, queueSlot = 0;
-    SlabRay r{{0, 0, 0}, {0, 0, 1}, {0, 0, 1}, false, false, false};
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
     float tMin = 0.0f, tMax = 0.0f;
     bool fast = false;
     int bestTri = -1;
@@ -71,55 +92,27 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const float4* __re
     // wavefront-uniform chunk of ray indices
     unsigned chunkBase = 0, chunkLeft = 0;
     bool exhausted = (total == 0);
+    constexpr int kDepth = ANYHIT ? kPendAnyHit : kPendClosest;  // leaves a lane may park (1..4)
 
-    auto finish = [&]() {  // the ray of this lane is done: publish its result, free the lane
-        if (ANYHIT) {
-            if (bestTri >= 0) occ[target ? (unsigned)target[queueSlot] : queueSlot] = 1;
-        } else {
-            hits[raySlot] = make_float4(i2f(bestTri), bestT, bestB, bestG);
-        }
-        state = EMPTY;
-    };
-    // one node for a searching lane (cs488.h:1669-1680)
-    auto box_step = [&]() {
-        const float4 lo = s.nodes[2 * (size_t)node];
-        const float4 hi = s.nodes[2 * (size_t)node + 1];
-        if (COUNT) nv++;
-        const int miss = f2i(lo.w);
-        const bool hit = fast ? slab_hit_fast(lo, hi, r) : slab_hit_ieee(lo, hi, r.o, r.d);
-        if (hit) {
-            const int link = f2i(hi.w);
-            if (link < 0) { state = LEAF; k = ~link; cont = miss; }
-            else node = link;
-        } else {
-            node = miss;
-        }
-        if (state == SEARCH && node == 0) finish();
-    };
-    // one triangle for a parked lane (cs488.h:1671-1675 / 1693-1697)
-    auto tri_step = [&]() {
-        const float4 q0 = s.leafTris[3 * (size_t)k];
-        const float4 q1 = s.leafTris[3 * (size_t)k + 1];
-        const float4 q2 = s.leafTris[3 * (size_t)k + 2];
-        if (COUNT) nt++;
-        float t, be, ga;
-        const bool acc = tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z}, r.o, r.d, tMin,
-                                  tMax, t, be, ga);
-        if (acc && (ANYHIT || t < bestT)) {
-            bestTri = f2i(q0.w); bestT = t; bestB = be; bestG = ga;
-        }
-        if (ANYHIT && acc) {
-            finish();
-        } else if (f2i(q1.w)) {  // last triangle of the leaf: the walk resumes at the leaf's idHit (= idMiss)
-            if (cont == 0) finish();
-            else { node = cont; state = SEARCH; }
-        } else {
-            ++k;
-        }
-    };
+    // (no lambdas here: variables captured by reference end up in a stack closure that the optimiser may fail to
+    // scalarise once it has merged "c ? x : y" over two captures into a load through a selected pointer)
+// the ray of this lane is done: publish its result, free the lane
+#define PT_FINISH()                                                                        \
+    do {                                                                                   \
+        if (ANYHIT) {                                                                      \
+            if (bestTri >= 0) occ[target ? (unsigned)target[queueSlot] : queueSlot] = 1;   \
+        } else {                                                                           \
+            hits[raySlot] = make_float4(i2f(bestTri), bestT, bestB, bestG);                \
+        }                                                                                  \
+        hasRay = false;                                                                    \
+        walking = false;                                                                   \
+        cur = -1;                                                                          \
+        nPend = 0;                                                                         \
+    } while (0)
+#define PT_PEND_FULL() (cur >= 0 && nPend >= kDepth - 1)
 
     while (true) {
-        const unsigned long long mEmpty = __ballot(state == EMPTY);
+        const unsigned long long mEmpty = __ballot(!hasRay);
         const int nEmpty = __popcll(mEmpty);
         if (nEmpty == 64 && exhausted) break;
         if (!exhausted && nEmpty >= kRefillLanes) {
@@ -138,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const float4* __re
             if (chunkLeft != 0) {
                 const unsigned rank = (unsigned)__popcll(mEmpty & ((1ull << lane) - 1ull));
                 const unsigned take = chunkLeft < (unsigned)nEmpty ? chunkLeft : (unsigned)nEmpty;
-                if (state == EMPTY && rank < take) {
+                if (!hasRay && rank < take) {
                     const unsigned j = chunkBase + rank;  // dense ray index
                     unsigned slot = j;
                     if (q.counts) {  // dense index -> shard by binary search over the prefix sums
@@ -153,33 +146,94 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene s, const float4* __re
                     raySlot = index ? (unsigned)index[slot] : slot;
                     const size_t rs = ANYHIT ? (size_t)slot : (size_t)raySlot;  // shadow rays live in queue order
                     const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
-                    r.o = vec3{r0.x, r0.y, r0.z}; tMin = r0.w;
-                    r.d = vec3{r1.x, r1.y, r1.z}; tMax = r1.w;
-                    fast = s.planesTame && fast_div_ok(r.o, r.d);
-                    r.y = vec3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
-                    r.nx = r.d.x < 0.0f; r.ny = r.d.y < 0.0f; r.nz = r.d.z < 0.0f;
+                    ox = r0.x; oy = r0.y; oz = r0.z; tMin = r0.w;
+                    dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
+                    fast = s.planesTame && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz});
+                    yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
                     bestTri = -1; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
                     node = 0;
-                    state = SEARCH;
+                    hasRay = true;
+                    walking = true;
                 }
                 chunkBase += take;
                 chunkLeft -= take;
             }
             if (nEmpty == 64) continue;  // nothing else to do yet
         }
-        // ---- box burst: searching lanes advance up to kBoxBurst nodes without re-voting ----
+        // ---- box burst: walking lanes with room to park a leaf advance up to kBoxBurst nodes (cs488.h:1669-1680) ----
 #pragma unroll
-        for (int b = 0; b < kBoxBurst; b++)
-            if (state == SEARCH) box_step();
-        // ---- triangle steps: when enough lanes are parked at a leaf, or nobody is searching ----
-        unsigned long long mLeaf = __ballot(state == LEAF);
-        if (mLeaf != 0ull && (__popcll(mLeaf) >= kLeafLanes || __ballot(state == SEARCH) == 0ull)) {
+        for (int b = 0; b < kBoxBurst; b++) {
+            if (walking && !PT_PEND_FULL()) {
+                float4v n0, n1;  // {min.x, max.x, min.y, max.y} {min.z, max.z, idMiss, link}
+                if (node < nTop) {  // top of the tree: from LDS
+                    n0 = topLds[2 * node];
+                    n1 = topLds[2 * node + 1];
+                } else {
+                    n0 = nodesGlobal[2 * (size_t)node];
+                    n1 = nodesGlobal[2 * (size_t)node + 1];
+                }
+                if (COUNT) nv++;
+                const bool hit = fast ? slab_hit_fast(n0, n1, ox, oy, oz, dx, dy, dz, yx, yy, yz)
+                                      : slab_hit_ieee(n0, n1, vec3{ox, oy, oz}, vec3{dx, dy, dz});
+                // bookkeeping under nested ifs on purpose: the kernel is bound by vector-ALU issue slots, and the
+                // exec-mask juggling of the ifs runs on the scalar unit beside it (the select form measured slower)
+                int next = f2i(n1.z);  // idMiss
+                if (hit) {
+                    const int link = f2i(n1.w);
+                    if (link < 0) {  // leaf: park its triangles, go on at idHit (= idMiss)
+                        if (cur < 0) {
+                            cur = ~link;
+                        } else {
+                            p2 = p1; p1 = p0; p0 = ~link;
+                            ++nPend;
+                        }
+                    } else {
+                        next = link;
+                    }
+                }
+                node = next;
+                if (next == 0) {
+                    walking = false;
+                    if (cur < 0) PT_FINISH();
+                }
+            }
+        }
+        // ---- triangle steps: when enough lanes hold parked leaves, or nobody can walk on ----
+        const unsigned long long mCanWalk = __ballot(walking && !PT_PEND_FULL());
+        unsigned long long mPend = __ballot(cur >= 0);
+        if (mPend != 0ull && (__popcll(mPend) >= kLeafLanes || mCanWalk == 0ull)) {
             do {
-                if (state == LEAF) tri_step();
-                mLeaf = __ballot(state == LEAF);
-            } while (__popcll(mLeaf) >= kLeafLanes);
+                if (cur >= 0) {  // one triangle of the oldest parked leaf (cs488.h:1671-1675 / 1693-1697)
+                    const float4 q0 = s.leafTris[3 * (size_t)cur];
+                    const float4 q1 = s.leafTris[3 * (size_t)cur + 1];
+                    const float4 q2 = s.leafTris[3 * (size_t)cur + 2];
+                    if (COUNT) nt++;
+                    float t, be, ga;
+                    const bool acc = tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z},
+                                              vec3{ox, oy, oz}, vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
+                    if (acc && (ANYHIT || t < bestT)) {
+                        bestTri = f2i(q0.w); bestT = t; bestB = be; bestG = ga;
+                    }
+                    if (ANYHIT && acc) {
+                        PT_FINISH();  // isHit returns at the first accepted triangle (cs488.h:1696)
+                    } else if (f2i(q1.w)) {  // last triangle of this leaf: on to the next parked leaf
+                        if (nPend > 0) {
+                            cur = (nPend == 1) ? p0 : (nPend == 2) ? p1 : p2;
+                            --nPend;
+                        } else {
+                            cur = -1;
+                            if (!walking) PT_FINISH();
+                        }
+                    } else {
+                        ++cur;
+                    }
+                }
+                mPend = __ballot(cur >= 0);
+            } while (__popcll(mPend) >= kLeafLanesKeep);
         }
     }
+#undef PT_FINISH
+#undef PT_PEND_FULL
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) {  // wave-level reduction, one atomic pair per wavefront
             nv += __shfl_down(nv, off);
@@ -258,8 +312,8 @@ __global__ __launch_bounds__(kBlock) void k_divcheck(unsigned seed, unsigned per
             }
         };
         const unsigned md = mant(r0, r2), ma = mant(r1, r2 >> 3);
-        const int ed = 127 - 40 + (int)((r2 >> 6) % 81u);           // |d| in [2^-40, 2^40]
-        const int ea = 127 - 63 + (int)((r2 >> 14) % 105u);         // |a| in [2^-63, 2^41]
+        const int ed = 127 + kDirLo + (int)((r2 >> 6) % (unsigned)(kDirHi - kDirLo + 1));   // |d| in [2^-40, 2^40]
+        const int ea = 127 + kNumLo + (int)((r2 >> 14) % (unsigned)(kNumHi - kNumLo + 1));  // |a| in [2^-84, 2^41]
         const float d = i2f((int)(((r2 >> 30) & 1u) << 31 | (unsigned)ed << 23 | md));
         float a = i2f((int)(((r2 >> 31) & 1u) << 31 | (unsigned)ea << 23 | ma));
         if ((r2 >> 22 & 63u) == 0u) a = 0.0f;
@@ -282,31 +336,31 @@ static inline unsigned grid_for(size_t n) {
     return (unsigned)g;
 }
 
-// persistent grid: enough wavefronts to fill the chip (256 CUs x 28 resident), never more than the rays need
+// persistent grid: two blocks per CU (their LDS fills it), never more than the rays need
 static inline unsigned trace_grid(size_t nMax) {
-    size_t g = (nMax + kBlock - 1) / kBlock;
+    size_t g = (nMax + kTraceBlock - 1) / kTraceBlock;
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;
+    if (g > 512) g = 512;
     return (unsigned)g;
 }
 void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
                           unsigned* cursor, float4* hits, unsigned long long* counters) {
     const unsigned g = trace_grid(q.space);
     if (counters)
-        hipLaunchKernelGGL((k_trace<false, true>), dim3(g), dim3(kBlock), 0, st, s, rays, index, nullptr, q, cursor, hits,
+        hipLaunchKernelGGL((k_trace<false, true>), dim3(g), dim3(kTraceBlock), 0, st, s, rays, index, nullptr, q, cursor, hits,
                            nullptr, counters);
     else
-        hipLaunchKernelGGL((k_trace<false, false>), dim3(g), dim3(kBlock), 0, st, s, rays, index, nullptr, q, cursor, hits,
+        hipLaunchKernelGGL((k_trace<false, false>), dim3(g), dim3(kTraceBlock), 0, st, s, rays, index, nullptr, q, cursor, hits,
                            nullptr, counters);
 }
 void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
                            unsigned* cursor, unsigned char* occ, unsigned long long* counters) {
     const unsigned g = trace_grid(q.space);
     if (counters)
-        hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kBlock), 0, st, s, rays, nullptr, target, q, cursor,
+        hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kTraceBlock), 0, st, s, rays, nullptr, target, q, cursor,
                            nullptr, occ, counters);
     else
-        hipLaunchKernelGGL((k_trace<true, false>), dim3(g), dim3(kBlock), 0, st, s, rays, nullptr, target, q, cursor,
+        hipLaunchKernelGGL((k_trace<true, false>), dim3(g), dim3(kTraceBlock), 0, st, s, rays, nullptr, target, q, cursor,
                            nullptr, occ, counters);
 }
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays) {

@@ -26,8 +26,13 @@ __device__ __forceinline__ float i2f(int i) { return __int_as_float(i); }
 // (q1), a second one rounds it correctly (Markstein, IBM J. R&D 34(1), 1990:
 // with y = RN(1/d), q faithful and r = a - q*d exact, RN(q + r*y) = RN(a/d)).
 // Preconditions, guaranteed by the callers (fast_div_ok): d finite, nonzero,
-// 2^-40 <= |d| <= 2^40, and a == 0 or 2^-63 <= |a| <= 2^41, so that no
-// intermediate overflows, underflows or becomes subnormal.  The sequence is
+// 2^-40 <= |d| <= 2^40, and a == 0 or 2^-84 <= |a| <= 2^41.  Then y, q0, q1
+// and q are normal (|q| >= 2^-124), nothing overflows (|q| <= 2^81), and the
+// residuals -- multiples of ulp(q)*ulp(d) >= 2^-131 that fit 24 bits -- are
+// exact (the kernels run with fp32 denormals enabled, denorm mode 3).
+// a = plane - o reaches this with o and the plane each 0 or of magnitude in
+// [2^-61, 2^40]: a nonzero difference of two such floats is a multiple of
+// ulp(2^-61) = 2^-84.  The sequence is
 // 1 mul + 4 fma; hipcc expands an IEEE `/` into ~11 instructions incl. a
 // quarter-rate v_rcp_f32.  tests/test_gpu_trace.py::test_fast_division_is_ieee
 // checks it against `/` on 2^33 operand pairs incl. the structured corner cases.
@@ -38,6 +43,9 @@ __device__ __forceinline__ float div_by_recip(float a, float d, float y) {
     const float r1 = __builtin_fmaf(-q1, d, a);
     return __builtin_fmaf(r1, y, q1);
 }
+constexpr int kTameLo = -61, kTameHi = 40;  // origins and box planes: 0 or magnitude in [2^kTameLo, 2^kTameHi]
+constexpr int kDirLo = -40, kDirHi = 40;    // direction components: magnitude in [2^kDirLo, 2^kDirHi]
+constexpr int kNumLo = -84, kNumHi = 41;    // resulting numerators: 0 or magnitude in [2^kNumLo, 2^kNumHi]
 // magnitude is 0 or inside [2^lo, 2^hi]
 __device__ __forceinline__ bool mag_zero_or_within(float v, int lo, int hi) {
     const unsigned e = ((unsigned)f2i(v) >> 23) & 0xffu;
@@ -49,18 +57,24 @@ __device__ __forceinline__ bool mag_within(float v, int lo, int hi) {
 }
 // may this ray use div_by_recip in the slab test?  (scene planes are checked on the host: DevScene::planesTame)
 __device__ __forceinline__ bool fast_div_ok(const vec3 o, const vec3 d) {
-    return mag_zero_or_within(o.x, -40, 40) && mag_zero_or_within(o.y, -40, 40) && mag_zero_or_within(o.z, -40, 40) &&
-           mag_within(d.x, -40, 40) && mag_within(d.y, -40, 40) && mag_within(d.z, -40, 40);
+    return mag_zero_or_within(o.x, kTameLo, kTameHi) && mag_zero_or_within(o.y, kTameLo, kTameHi) &&
+           mag_zero_or_within(o.z, kTameLo, kTameHi) && mag_within(d.x, kDirLo, kDirHi) &&
+           mag_within(d.y, kDirLo, kDirHi) && mag_within(d.z, kDirLo, kDirHi);
 }
 
+// native vector types: loadable through address-space-qualified pointers (LDS / global), and the packed fp32 math
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
 // AABB::intersect, cs488.h:571-608 (only the boolean is needed by the threaded walk), literal form.
-__device__ __forceinline__ bool slab_hit_ieee(const float4 lo, const float4 hi, const vec3 o, const vec3 d) {
-    float tx1 = (lo.x - o.x) / d.x;
-    float ty1 = (lo.y - o.y) / d.y;
-    float tz1 = (lo.z - o.z) / d.z;
-    float tx2 = (hi.x - o.x) / d.x;
-    float ty2 = (hi.y - o.y) / d.y;
-    float tz2 = (hi.z - o.z) / d.z;
+// Node record (device_scene.hpp): n0 = {min.x, max.x, min.y, max.y}, n1 = {min.z, max.z, idMiss, link}.
+__device__ __forceinline__ bool slab_hit_ieee(const float4v n0, const float4v n1, const vec3 o, const vec3 d) {
+    float tx1 = (n0.x - o.x) / d.x;
+    float ty1 = (n0.z - o.y) / d.y;
+    float tz1 = (n1.x - o.z) / d.z;
+    float tx2 = (n0.y - o.x) / d.x;
+    float ty2 = (n0.w - o.y) / d.y;
+    float tz2 = (n1.y - o.z) / d.z;
     if (tx1 > tx2) { const float tmp = tx1; tx1 = tx2; tx2 = tmp; }
     if (ty1 > ty2) { const float tmp = ty1; ty1 = ty2; ty2 = tmp; }
     if (tz1 > tz2) { const float tmp = tz1; tz1 = tz2; tz2 = tmp; }
@@ -72,24 +86,32 @@ __device__ __forceinline__ bool slab_hit_ieee(const float4 lo, const float4 hi, 
 }
 // The same predicate for a ray that satisfies fast_div_ok in a scene with tame planes.  All six quotients are
 // then finite and bit-identical to the IEEE ones (div_by_recip), which allows two exact shortcuts:
-//  * lo <= hi and RN subtraction/division are monotone, so after the reference's swap the smaller quotient of
-//    an axis is the lo-plane's when d > 0 and the hi-plane's when d < 0 (equal quotients: the swap is moot):
-//    the planes are selected by the ray's direction signs instead of comparing and swapping;
-//  * without NaNs the if-chains are max3 / min3 (a +-0 tie cannot change any of the comparisons that follow).
-struct SlabRay {
-    vec3 o, d, y;
-    bool nx, ny, nz;  // d.x < 0, ...
-};
-__device__ __forceinline__ bool slab_hit_fast(const float4 lo, const float4 hi, const SlabRay& r) {
-    const float nearx = div_by_recip((r.nx ? hi.x : lo.x) - r.o.x, r.d.x, r.y.x);
-    const float neary = div_by_recip((r.ny ? hi.y : lo.y) - r.o.y, r.d.y, r.y.y);
-    const float nearz = div_by_recip((r.nz ? hi.z : lo.z) - r.o.z, r.d.z, r.y.z);
-    const float farx = div_by_recip((r.nx ? lo.x : hi.x) - r.o.x, r.d.x, r.y.x);
-    const float fary = div_by_recip((r.ny ? lo.y : hi.y) - r.o.y, r.d.y, r.y.y);
-    const float farz = div_by_recip((r.nz ? lo.z : hi.z) - r.o.z, r.d.z, r.y.z);
-    const float t1 = __builtin_fmaxf(__builtin_fmaxf(nearx, neary), nearz);
-    const float t2 = __builtin_fminf(__builtin_fminf(farx, fary), farz);
-    return !(t1 > t2) && !((t1 < 0.0f) && (t2 < 0.0f));
+//  * without NaNs the reference's swap of an axis' two quotients is min / max of the pair, and its if-chains are
+//    max3 / min3 (a +-0 tie cannot change any of the comparisons that follow);
+//  * the (min, max) planes of an axis sit in adjacent registers, so the subtraction and the five steps of the
+//    division run as packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma_f32: two lanes of IEEE fp32 per
+//    issue slot, each rounding exactly like the scalar instruction) -- 18 packed instructions for six quotients.
+__device__ __forceinline__ float2v div_by_recip2(const float2v a, const float d, const float y) {
+    const float2v dd = {d, d}, yy = {y, y};
+    const float2v q0 = a * yy;
+    const float2v r0 = __builtin_elementwise_fma(-q0, dd, a);
+    const float2v q1 = __builtin_elementwise_fma(r0, yy, q0);
+    const float2v r1 = __builtin_elementwise_fma(-q1, dd, a);
+    return __builtin_elementwise_fma(r1, yy, q1);
+}
+// o, d: the ray; y = RN(1/d) per component.  (Scalars by value: a struct of them, passed by reference, was left
+// on the stack by the compiler.)
+__device__ __forceinline__ bool slab_hit_fast(const float4v n0, const float4v n1, const float ox, const float oy,
+                                              const float oz, const float dx, const float dy, const float dz,
+                                              const float yx, const float yy, const float yz) {
+    const float2v qx = div_by_recip2(float2v{n0.x, n0.y} - float2v{ox, ox}, dx, yx);
+    const float2v qy = div_by_recip2(float2v{n0.z, n0.w} - float2v{oy, oy}, dy, yy);
+    const float2v qz = div_by_recip2(float2v{n1.x, n1.y} - float2v{oz, oz}, dz, yz);
+    const float t1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(qx.x, qx.y), __builtin_fminf(qy.x, qy.y)),
+                                     __builtin_fminf(qz.x, qz.y));
+    const float t2 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(qx.x, qx.y), __builtin_fmaxf(qy.x, qy.y)),
+                                     __builtin_fmaxf(qz.x, qz.y));
+    return !(t1 > t2) & !((t1 < 0.0f) & (t2 < 0.0f));
 }
 
 // raytraceTriangle, cs488.h:782-812, on the precomputed edges a = p0-p1, b = p0-p2.

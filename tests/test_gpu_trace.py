@@ -15,7 +15,7 @@ _cache = {}
 def setup_scene(B, sf, name, env=None):
     key = (name, env is not None)
     if key not in _cache:
-        arrays = sf.load_scene_arrays(name)
+        arrays = sf.sponza_standin(1) if name == "sponza-standin-trace" else sf.load_scene_arrays(name)
         scene = sf.product_scene_from_mesh_arrays(*arrays, env=env)
         ctx = B.Context(scene, device=0)
         orc = sf.oracle_scene_from_mesh_arrays(*arrays, env=env)
@@ -133,3 +133,66 @@ def test_fast_division_is_ieee(B, sf):
     scene, ctx, orc = setup_scene(B, sf, "cube")
     for seed in (1, 2):
         assert ctx.selftest_fast_division(1 << 32, seed) == 0
+
+
+def test_scene_outside_reciprocal_preconditions_takes_ieee_path(B, ob, sf):
+    """one extra triangle with a vertex coordinate of 1e-25 puts box planes below 2^-61: the library must fall
+    back to the literal IEEE slab test for every ray (exact_reciprocal False) and still match the oracle bit for
+    bit; the same holds for the scene scaled by 2^43 (planes above 2^40)"""
+    base = sf.load_scene_arrays("cornellbox")
+    for variant in ("tiny-plane", "huge"):
+        arrays = [np.array(a) if isinstance(a, np.ndarray) else a for a in base]
+        cam = B.default_camera(96, 64)
+        k = np.float32(1.0)
+        if variant == "tiny-plane":
+            extra = np.array([[1e-25, 0.5, 0.5], [0.1, 0.5, 0.5], [0.1, 0.6, 0.5]], np.float32)
+            arrays[0] = np.concatenate([np.asarray(arrays[0], np.float32).reshape(-1, 3, 3), extra[None]]).reshape(-1)
+            arrays[1] = np.concatenate([np.asarray(arrays[1], np.float32).reshape(-1, 3, 3),
+                                        np.tile(np.array([0, 0, 1], np.float32), (1, 3, 1))]).reshape(-1)
+            arrays[2] = np.concatenate([np.asarray(arrays[2], np.float32).reshape(-1, 3, 2),
+                                        np.zeros((1, 3, 2), np.float32)]).reshape(-1)
+            arrays[3] = np.concatenate([np.asarray(arrays[3], np.int32), np.zeros(1, np.int32)])
+        else:
+            k = np.float32(2.0 ** 43)
+            arrays[0] = (np.asarray(arrays[0], np.float32) * k).astype(np.float32)
+        scene = sf.product_scene_from_mesh_arrays(*arrays)
+        assert not scene.exact_reciprocal, variant
+        ctx = B.Context(scene, device=0)
+        orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+        o, d = ctx.eye_rays(cam)
+        o = (o * k).astype(np.float32)
+        a = ctx.trace(o, d)
+        b = orc.intersect(o, d)
+        assert (b[0] >= 0).sum() > 1000, variant
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and \
+            np.array_equal(bits(a[2]), bits(b[2])), variant
+
+
+def test_rays_straddling_reciprocal_preconditions(B, ob, sf):
+    """per-ray choice between the reciprocal and the IEEE slab division: directions and origins with components
+    at, just inside and just outside the precondition bounds (2^-40 / 2^40 for d, 2^-61 / 2^40 for o), zeros,
+    denormals -- all in one batch so that lanes of one wavefront mix both code paths"""
+    scene, ctx, orc = setup_scene(B, sf, "sponza-standin-trace")
+    assert scene.exact_reciprocal
+    rng = np.random.default_rng(11)
+    n = 1 << 14
+    o = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32) * np.float32(0.5) + np.array([0, 1.0, 0], np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    mags_d = np.array([2.0 ** -41, 2.0 ** -40, 2.0 ** -39, 1e-30, 1e-42, 0.0, 2.0 ** 40, 2.0 ** 41], np.float32)
+    mags_o = np.array([2.0 ** -62, 2.0 ** -61, 2.0 ** -60, 1e-40, 0.0, -(2.0 ** -61), 8.7e-18], np.float32)
+    sel = rng.integers(0, 4, n)
+    ax = rng.integers(0, 3, n)
+    rows = np.arange(n)
+    md = mags_d[rng.integers(0, len(mags_d), n)] * rng.choice(np.array([-1, 1], np.float32), n)
+    mo = mags_o[rng.integers(0, len(mags_o), n)]
+    d[rows[sel == 1], ax[sel == 1]] = md[sel == 1]
+    o[rows[sel == 2], ax[sel == 2]] = mo[sel == 2]
+    d[rows[sel == 3], ax[sel == 3]] = md[sel == 3]
+    o[rows[sel == 3], (ax[sel == 3] + 1) % 3] = mo[sel == 3]
+    a = ctx.trace(o, d)
+    b = orc.intersect(o, d)
+    assert (b[0] >= 0).sum() > n // 4
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[2]), bits(b[2]))
+    occ = ctx.occluded(o, d, 1e-4, 2.5)
+    assert np.array_equal(occ, orc.occluded(o, d, 1e-4, 2.5))

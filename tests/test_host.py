@@ -214,3 +214,12 @@ def test_scene_validation_rejects_bad_links(B, sf):
     d.n_lights = 17
     assert B.lib().mipt_scene_create(C.byref(d), C.byref(h)) == -5  # MIPT_ERR_LIMIT
     assert b"16" in B.lib().mipt_last_error()
+
+
+def test_bench_scene_qualifies_for_exact_reciprocal(B, sf):
+    """the bench workload must run the traversal kernel's reciprocal slab division (a scene with one plane outside
+    [2^-61, 2^40] silently falls back to IEEE division for every ray); a scaled-down copy must not qualify"""
+    arrays = list(sf.sponza_standin(1))
+    assert sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT).exact_reciprocal
+    arrays[0] = (np.asarray(arrays[0], np.float32) * np.float32(2.0 ** -70)).astype(np.float32)
+    assert not sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT).exact_reciprocal
