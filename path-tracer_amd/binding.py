@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmipt.so")
+# MIPT_LIB_PATH: developer override (tools/tune_trace.sh benches variant builds); unset = the in-tree library
+LIB_PATH = os.environ.get("MIPT_LIB_PATH") or os.path.join(_HERE, "libmipt.so")
 
 MAT_LAMBERTIAN, MAT_METAL, MAT_GLASS, MAT_LIGHT = 0, 1, 2, 3
 MODE_PRIMARY, MODE_DIRECT, MODE_PATH = 0, 1, 2

@@ -48,7 +48,10 @@ struct DevScene {
 // hit record, 16 B: {bits(tri_id or -1), t, beta, gamma}
 
 constexpr int kBlock = 256;
-constexpr int kTraceBlock = 768;  // k_trace: 12 wavefronts per block, two blocks per CU (LDS: 2 x ~64 KB of 160 KB)
+#ifndef PT_TUNE_BLOCK
+#define PT_TUNE_BLOCK 1024
+#endif
+constexpr int kTraceBlock = PT_TUNE_BLOCK;  // k_trace: 16 wavefronts per block, two blocks per CU (LDS: 2 x ~64 KB of 160 KB)
 constexpr int kTopNodes = 2032;   // nodes k_trace keeps in LDS (32 B each; with the shard prefix sums just under 64 KB)
 
 }  // namespace ptd

@@ -2,7 +2,7 @@
 // "occluded") and the small kernels around the parity entry points: eye-ray
 // generation, HitInfo resolution, environment lookup.
 //
-// Launch shape: k_trace runs 768-thread blocks (12 wavefronts of 64 lanes), two
+// Launch shape: k_trace runs 1024-thread blocks (16 wavefronts of 64 lanes), two
 // per CU, one ray per lane at a time; the small kernels use 256-thread blocks.  Queue lengths live in device memory (sharded counters), so
 // a whole frame is enqueued without host syncs.
 #include "kernels.hpp"
@@ -36,15 +36,41 @@ namespace ptd {
 // the shard counters are prefix-summed into LDS so that rays are addressed by
 // a dense index.  index (nullable): queue slot -> ray slot; the result goes to
 // hits[ray slot] (closest hit) or occ[target[queue slot]] (any hit).
-constexpr int kRefillLanes = 16;  // refill when this many lanes are empty
-constexpr int kLeafLanes = 40;      // start testing triangles when this many lanes hold parked leaves ...
-constexpr int kLeafLanesKeep = 16;  // ... and keep going while this many still do
-constexpr int kBoxBurst = 4;        // box steps between two votes
-constexpr int kPendClosest = 4;     // leaves a lane may park before it must wait (closest hit)
-constexpr int kPendAnyHit = 1;      // any-hit rays end at their first accepted triangle: parking more only wastes box steps
+// Scheduling constants (tools/tune_trace.sh builds variants with -DPT_TUNE_...; the defaults are the measured best)
+#ifndef PT_TUNE_REFILL
+#define PT_TUNE_REFILL 16
+#endif
+#ifndef PT_TUNE_LEAF
+#define PT_TUNE_LEAF 40
+#endif
+#ifndef PT_TUNE_LEAF_KEEP
+#define PT_TUNE_LEAF_KEEP 16
+#endif
+#ifndef PT_TUNE_BURST
+#define PT_TUNE_BURST 4
+#endif
+#ifndef PT_TUNE_PEND_ANYHIT
+#define PT_TUNE_PEND_ANYHIT 1
+#endif
+#ifndef PT_TUNE_LEAF_ANYHIT
+#define PT_TUNE_LEAF_ANYHIT PT_TUNE_LEAF
+#endif
+#ifndef PT_TUNE_LEAF_KEEP_ANYHIT
+#define PT_TUNE_LEAF_KEEP_ANYHIT PT_TUNE_LEAF_KEEP
+#endif
+constexpr int kRefillLanes = PT_TUNE_REFILL;  // refill when this many lanes are empty
+constexpr int kBoxBurst = PT_TUNE_BURST;      // box steps between two votes
+constexpr int kPendClosest = 4;               // leaves a lane may park before it must wait (closest hit)
+constexpr int kPendAnyHit = PT_TUNE_PEND_ANYHIT;  // any-hit rays end at their first accepted triangle: parking more wastes box steps
 
+// 8 wavefronts per SIMD (two 1024-thread blocks per CU): the compiler keeps the kernel within 64 VGPRs (the
+// closest-hit variant spills 7 rarely used values); measured 2-3 % faster than 6 per SIMD with 768-thread blocks
+#ifndef PT_TUNE_WAVES_PER_EU
+#define PT_TUNE_WAVES_PER_EU 8
+#endif
+#define PT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(PT_TUNE_WAVES_PER_EU, PT_TUNE_WAVES_PER_EU)))
 template <bool ANYHIT, bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(DevScene s, const float4* __restrict__ rays,
+__global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s, const float4* __restrict__ rays,
                                                   const int* __restrict__ index, const int* __restrict__ target,
                                                   QueueView q, unsigned* __restrict__ cursor,
                                                   float4* __restrict__ hits, unsigned char* __restrict__ occ,
@@ -89,10 +115,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DevScene s, const float4*
     int bestTri = -1;
     float bestT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;
     unsigned nv = 0, nt = 0;
+#ifdef PT_TUNE_DUMMY_VALU
+    float dummyValu = 0.5f;
+#endif
     // wavefront-uniform chunk of ray indices
     unsigned chunkBase = 0, chunkLeft = 0;
     bool exhausted = (total == 0);
     constexpr int kDepth = ANYHIT ? kPendAnyHit : kPendClosest;  // leaves a lane may park (1..4)
+    // triangle steps start when this many lanes hold parked leaves and go on while kLeafLanesKeep still do
+    constexpr int kLeafLanes = ANYHIT ? PT_TUNE_LEAF_ANYHIT : PT_TUNE_LEAF;
+    constexpr int kLeafLanesKeep = ANYHIT ? PT_TUNE_LEAF_KEEP_ANYHIT : PT_TUNE_LEAF_KEEP;
 
     // (no lambdas here: variables captured by reference end up in a stack closure that the optimiser may fail to
     // scalarise once it has merged "c ? x : y" over two captures into a load through a selected pointer)
@@ -173,6 +205,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DevScene s, const float4*
                     n1 = nodesGlobal[2 * (size_t)node + 1];
                 }
                 if (COUNT) nv++;
+#ifdef PT_TUNE_DUMMY_VALU  // diagnostic builds only (tools/tune_trace.sh): extra independent vector instructions per box step
+#pragma unroll
+                for (int dv = 0; dv < PT_TUNE_DUMMY_VALU; dv++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummyValu));
+#endif
                 const bool hit = fast ? slab_hit_fast(n0, n1, ox, oy, oz, dx, dy, dz, yx, yy, yz)
                                       : slab_hit_ieee(n0, n1, vec3{ox, oy, oz}, vec3{dx, dy, dz});
                 // bookkeeping under nested ifs on purpose: the kernel is bound by vector-ALU issue slots, and the
