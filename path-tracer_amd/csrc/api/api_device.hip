@@ -731,19 +731,23 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
             trace_closest(c, pb.rays, pb.qExt[it & 1],
                           QueueView{pb.counters + counter_index(it, 0, 0), pb.regionSize, pb.space},
                           pb.counters + counter_index(it, 3, 0), pb.hit);
+            const bool pathMode = rp->mode == MIPT_MODE_PATH;
             {
                 Timer tm(c, 2);
                 count_launch(c, 2);
-                launch_shade_a(c->stream, c->ds, fp, pb, it);
+                if (pathMode) launch_shade_path(c->stream, c->ds, fp, pb, it, false);
+                else launch_shade_a(c->stream, c->ds, fp, pb, it);
             }
             if (rp->mode != MIPT_MODE_PRIMARY) {
                 trace_occluded(c, pb.shRays, pb.shTarget,
                                QueueView{pb.counters + counter_index(it, 2, 0), pb.regionSize * (unsigned)nl,
                                          pb.space * (unsigned)nl},
                                pb.counters + counter_index(it, 4, 0), pb.occ);
-                Timer tm(c, 2);
-                count_launch(c, 2);
-                launch_shade_b(c->stream, c->ds, fp, pb, it);
+                if (!pathMode) {
+                    Timer tm(c, 2);
+                    count_launch(c, 2);
+                    launch_shade_b(c->stream, c->ds, fp, pb, it);
+                }
             }
             itDone = it + 1;
             if (unbounded && it >= 8 && (it & 3) == 0 && it < lastIter) {
@@ -759,6 +763,8 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
         }
         if (rp->mode == MIPT_MODE_PATH) {
             Timer tm(c, 2);
+            count_launch(c, 2);
+            launch_shade_path(c->stream, c->ds, fp, pb, itDone, true);  // paths that ended at a Lambertian vertex of the last bounce
             count_launch(c, 2);
             launch_resolve_samples(c->stream, fp, pb);
         }

@@ -93,6 +93,9 @@ void launch_divcheck(hipStream_t st, unsigned seed, unsigned blocks, unsigned pe
 void launch_generate(hipStream_t st, const CameraDev& cam, const FrameParams& fp, const PathBuffers& pb);
 void launch_shade_a(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter);
 void launch_shade_b(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter);
+// path mode: the single shading kernel of bounce `iter` (kernels_integrate.hip); finalsOnly: only resolve the paths
+// that ended at a Lambertian vertex of bounce iter-1
+void launch_shade_path(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter, bool finalsOnly);
 // totals[0] += sum of extension-queue lengths, totals[1] += sum of shadow-queue lengths over iterations [0, nIter)
 void launch_resolve_samples(hipStream_t st, const FrameParams& fp, const PathBuffers& pb);
 void launch_fold_counters(hipStream_t st, const unsigned* counters, int nIter, unsigned long long* totals);

@@ -20,7 +20,6 @@ namespace ptd {
 
 enum : int { FLAG_NEGD = 1,        // currDir / viewDir of the vertex is -ray.d
              FLAG_FROM_METAL = 2 };  // direct mode: the ray was shot by a metal vertex
-enum : int { MISS_LAMBERT = 0, MISS_SPECULAR = 1 };
 constexpr float kFltMax = 3.402823466e+38f;
 
 // Queue slot for each lane whose pred is set: ballot + popcount, ONE atomicAdd
@@ -126,60 +125,88 @@ __device__ __forceinline__ void emit_extension(const PathBuffers& pb, unsigned p
 }
 
 // ---- path mode ----
-__global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams fp, PathBuffers pb, int it) {
+// ONE shading kernel per bounce: shade(it) runs after extend(it) and before occluded(it).  A Lambertian vertex
+// computes its light terms, emits its shadow rays AND (unless the path ends here) samples and emits the next
+// extension ray in the same pass -- the sampled direction does not depend on the shadow rays' outcome.  The
+// direct light L of that vertex (C:2303-2309) is summed one bounce later, when the next shade reads contrib[] and
+// the occlusion flags: the same additions in the same order, only later.  Paths that end at a Lambertian vertex
+// (bounce cap, Russian roulette) wait in the "fin" queue for their shadow rays and are resolved by the next
+// shade call; the host issues one last finals-only call after the loop.
+enum : int { FLAG_PEND_LAMBERT = 4 };  // the previous vertex was Lambertian: its L is still in contrib[] / occ[]
+
+__device__ __forceinline__ vec3 pending_light(const PathBuffers& pb, unsigned p, int nl) {
+    vec3 L{0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < nl; k++) {  // C:2303-2309
+        const float4 c = pb.contrib[(size_t)p * nl + k];
+        if (f2i(c.w) && pb.occ[(size_t)p * nl + k]) continue;
+        L = L + xyz(c);
+    }
+    return L;
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams fp, PathBuffers pb, int it, int finalsOnly) {
+    const int nl = pb.nLights;
+    // ---- paths that ended at a Lambertian vertex of bounce it-1: their shadow rays are traced now ----
+    if (it > 0) {
+        const unsigned* cFin = pb.counters + counter_index(it - 1, 1, 0);
+        for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < pb.space; i += gridDim.x * kBlock) {
+            if (!slot_live(cFin, pb.regionSize, i)) continue;
+            const unsigned p = (unsigned)pb.qAct[i];
+            finish_path(pb, p, xyz(pb.cnst[p]) + xyz(pb.mult[p]) * pending_light(pb, p, nl));  // C:2316
+        }
+    }
+    if (finalsOnly) return;
+
     const unsigned* cCur = pb.counters + counter_index(it, 0, 0);
     const int* q = pb.qExt[it & 1];
     int* qNext = pb.qExt[(it + 1) & 1];
     unsigned* cNext = pb.counters + counter_index(it + 1, 0, 0);
-    unsigned* cAct = pb.counters + counter_index(it, 1, 0);
+    unsigned* cFinOut = pb.counters + counter_index(it, 1, 0);
     unsigned* cSh = pb.counters + counter_index(it, 2, 0);
-    const int nl = pb.nLights;
     const bool capped = (fp.maxBounces >= 0) && (it >= fp.maxBounces);
 
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < pb.space; i += gridDim.x * kBlock) {
         const bool valid = slot_live(cCur, pb.regionSize, i);
-        bool toExt = false, toAct = false;
+        bool toExt = false, toFin = false;
         unsigned p = 0;
-        int pix = 0;
-        vec3 P{0, 0, 0}, N{0, 0, 0};
         if (valid) {
             p = (unsigned)q[i];
-            pix = pb.pixel[p];
-            const float4 r1 = pb.rays[2 * (size_t)p + 1];
-            const vec3 d = xyz(r1);
+            const vec3 d = xyz(pb.rays[2 * (size_t)p + 1]);
             const float4 h = pb.hit[p];
             const int tri = f2i(h.x);
             vec3 mult{1.0f, 1.0f, 1.0f}, cnst{0.0f, 0.0f, 0.0f};
             float eta = 1.0f;
             int flags = FLAG_NEGD;
+            unsigned dim = 0;  // rng dimension
             bool alive = true;
             if (it == 0) {
                 if (tri < 0) {  // C:2244: miss pixels show the background, unaccumulated
                     const vec3 bg = get_background(s, -d);
                     pb.res[p] = make_float4(bg.x, bg.y, bg.z, i2f(RES_BACKGROUND));
                     alive = false;
-                } else {
-                    pb.hitMul[p] = make_float4(1.0f, 1.0f, 1.0f, i2f(0));  // rng dimension 0
                 }
             } else {
-                const float4 m4 = pb.mult[p], c4 = pb.cnst[p], l4 = pb.pendL[p];
+                const float4 m4 = pb.mult[p], c4 = pb.cnst[p];
                 mult = xyz(m4); eta = m4.w; cnst = xyz(c4); flags = f2i(c4.w);
-                const vec3 L = xyz(l4);
-                const int missMode = f2i(l4.w);
+                const bool pendLambert = (flags & FLAG_PEND_LAMBERT) != 0;
+                vec3 L{0.0f, 0.0f, 0.0f};
+                if (pendLambert) L = pending_light(pb, p, nl);
                 if (tri < 0) {
-                    const vec3 result = (missMode == MISS_LAMBERT) ? cnst + mult * L : cnst + mult * get_background(s, d);
+                    const vec3 result = pendLambert ? cnst + mult * L : cnst + mult * get_background(s, d);
                     finish_path(pb, p, result);
                     alive = false;
                 } else {
-                    if (missMode == MISS_LAMBERT) cnst = cnst + L * mult;  // C:2322
-                    mult = mult * xyz(pb.hitMul[p]);                       // C:2323 / C:2348
+                    if (pendLambert) cnst = cnst + L * mult;  // C:2322
+                    const float4 hm = pb.hitMul[p];
+                    mult = mult * xyz(hm);                    // C:2323 / C:2348
+                    dim = (unsigned)f2i(hm.w);
                 }
             }
             if (alive) {
                 const HitInfo hi = reconstruct_hit(s, tri, h.y, h.z, h.w, d);
                 const MaterialDev m = load_material(s, hi.material);
                 const vec3 currDir = (flags & FLAG_NEGD) ? -d : d;
-                P = hi.P; N = hi.N;
+                const vec3 P = hi.P, N = hi.N;
                 if (m.type == MIPT_MAT_LAMBERTIAN) {
                     vec3 texture{1.0f, 1.0f, 1.0f};
                     if (m.texOfs >= 0) texture = texture * fetch_texture(s, m, hi.T);
@@ -203,21 +230,34 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
                             pb.shTarget[sl] = (int)((size_t)p * nl + k);
                         }
                     }
-                    pb.vP[p] = pack(P, i2f(hi.material));
-                    pb.vN[p] = pack(N, 0.0f);
-                    pb.vTex[p] = pack(texture, 0.0f);
+                    const int pix = pb.pixel[p];
+                    const unsigned sample = fp.sample + p / fp.nTilePaths;
+                    bool done = capped;
+                    if (!done && it > 5) {  // C:2311-2314, no weight compensation
+                        if (counter_rand(fp.seedHash, (unsigned)pix, sample, dim++) < .25f) done = true;
+                    }
                     pb.mult[p] = pack(mult, eta);
-                    pb.cnst[p] = pack(cnst, i2f(flags));
-                    toAct = true;
+                    if (done) {
+                        pb.cnst[p] = pack(cnst, i2f(FLAG_PEND_LAMBERT));
+                        toFin = true;
+                    } else {
+                        const float u1 = counter_rand(fp.seedHash, (unsigned)pix, sample, dim++);
+                        const float u2 = counter_rand(fp.seedHash, (unsigned)pix, sample, dim++);
+                        const vec3 smp = sample_lambert(N, u1, u2);
+                        const vec3 sample_brdf = m.Kd / kPI;
+                        const float pdf = 1.0f / kPI;
+                        emit_extension(pb, p, P, 0.001f, smp);
+                        pb.hitMul[p] = pack((texture * sample_brdf) / pdf, i2f((int)dim));
+                        pb.cnst[p] = pack(cnst, i2f(FLAG_PEND_LAMBERT));  // the next vertex reads currDir = ray.d
+                        toExt = true;
+                    }
                 } else if (m.type == MIPT_MAT_METAL) {
                     if (capped) {
                         finish_path(pb, p, cnst);
                     } else {
                         const vec3 smp = mirror(-currDir, N);  // C:496
                         emit_extension(pb, p, P, 0.001f, smp);
-                        pb.pendL[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(MISS_SPECULAR));
-                        const float4 hm = pb.hitMul[p];
-                        pb.hitMul[p] = pack(m.Ks, hm.w);
+                        pb.hitMul[p] = pack(m.Ks, i2f((int)dim));
                         pb.mult[p] = pack(mult, eta);
                         pb.cnst[p] = pack(cnst, i2f(0));
                         toExt = true;
@@ -230,9 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
                         const vec3 w = -currDir;
                         const float ratio = eta / eta2;
                         const float inside = snell_inside(ratio, pt::dot(w, N));
-                        const float4 hm = pb.hitMul[p];
-                        pb.hitMul[p] = make_float4(1.0f, 1.0f, 1.0f, hm.w);
-                        pb.pendL[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(MISS_SPECULAR));
+                        pb.hitMul[p] = make_float4(1.0f, 1.0f, 1.0f, i2f((int)dim));
                         if (inside >= 0.0f) {  // C:2366-2377; the ray direction is -refracted
                             emit_extension(pb, p, P, 0.01f, refract_dir(w, N, ratio, inside));
                             pb.mult[p] = pack(mult, eta2);
@@ -251,60 +289,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_path(DevScene s, FrameParams
         }
         const unsigned sExt = wave_append(cNext, pb.regionSize, (i >> 6) % (unsigned)kShards, toExt);
         if (toExt) qNext[sExt] = (int)p;
-        const unsigned sAct = wave_append(cAct, pb.regionSize, (i >> 6) % (unsigned)kShards, toAct);
-        if (toAct) pb.qAct[sAct] = (int)p;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_shade_b_path(DevScene s, FrameParams fp, PathBuffers pb, int it) {
-    const unsigned* cCur = pb.counters + counter_index(it, 1, 0);
-    int* qNext = pb.qExt[(it + 1) & 1];
-    unsigned* cNext = pb.counters + counter_index(it + 1, 0, 0);
-    const int nl = pb.nLights;
-    const bool capped = (fp.maxBounces >= 0) && (it >= fp.maxBounces);
-
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < pb.space; i += gridDim.x * kBlock) {
-        const bool valid = slot_live(cCur, pb.regionSize, i);
-        bool toExt = false;
-        unsigned p = 0;
-        if (valid) {
-            p = (unsigned)pb.qAct[i];
-            const int pix = pb.pixel[p];
-            const float4 m4 = pb.mult[p], c4 = pb.cnst[p];
-            const vec3 mult = xyz(m4), cnst = xyz(c4);
-            vec3 L{0.0f, 0.0f, 0.0f};
-            for (int k = 0; k < nl; k++) {  // C:2303-2309
-                const float4 c = pb.contrib[(size_t)p * nl + k];
-                if (f2i(c.w) && pb.occ[(size_t)p * nl + k]) continue;
-                L = L + xyz(c);
-            }
-            const float4 hm = pb.hitMul[p];
-            unsigned dim = (unsigned)f2i(hm.w);
-            const unsigned sample = fp.sample + p / fp.nTilePaths;
-            bool done = capped;
-            if (!done && it > 5) {  // C:2311-2314, no weight compensation
-                if (counter_rand(fp.seedHash, (unsigned)pix, sample, dim++) < .25f) done = true;
-            }
-            if (done) {
-                finish_path(pb, p, cnst + mult * L);
-            } else {
-                const float4 p4 = pb.vP[p];
-                const vec3 P = xyz(p4), N = xyz(pb.vN[p]), texture = xyz(pb.vTex[p]);
-                const MaterialDev m = load_material(s, f2i(p4.w));
-                const float u1 = counter_rand(fp.seedHash, (unsigned)pix, sample, dim++);
-                const float u2 = counter_rand(fp.seedHash, (unsigned)pix, sample, dim++);
-                const vec3 smp = sample_lambert(N, u1, u2);
-                const vec3 sample_brdf = m.Kd / kPI;
-                const float pdf = 1.0f / kPI;
-                emit_extension(pb, p, P, 0.001f, smp);
-                pb.pendL[p] = pack(L, i2f(MISS_LAMBERT));
-                pb.hitMul[p] = pack((texture * sample_brdf) / pdf, i2f((int)dim));
-                pb.cnst[p] = pack(cnst, i2f(0));
-                toExt = true;
-            }
-        }
-        const unsigned sExt = wave_append(cNext, pb.regionSize, i / pb.regionSize, toExt);
-        if (toExt) qNext[sExt] = (int)p;
+        const unsigned sFin = wave_append(cFinOut, pb.regionSize, (i >> 6) % (unsigned)kShards, toFin);
+        if (toFin) pb.qAct[sFin] = (int)p;
     }
 }
 
@@ -469,13 +455,14 @@ void launch_generate(hipStream_t st, const CameraDev& cam, const FrameParams& fp
 }
 void launch_shade_a(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter) {
     const unsigned g = grid_for(pb.space);
-    if (fp.mode == 2) hipLaunchKernelGGL(k_shade_a_path, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
-    else hipLaunchKernelGGL(k_shade_a_direct, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
+    hipLaunchKernelGGL(k_shade_a_direct, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
 }
 void launch_shade_b(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter) {
     const unsigned g = grid_for(pb.space);
-    if (fp.mode == 2) hipLaunchKernelGGL(k_shade_b_path, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
-    else hipLaunchKernelGGL(k_shade_b_direct, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
+    hipLaunchKernelGGL(k_shade_b_direct, dim3(g), dim3(kBlock), 0, st, s, fp, pb, iter);
+}
+void launch_shade_path(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter, bool finalsOnly) {
+    hipLaunchKernelGGL(k_shade_path, dim3(grid_for(pb.space)), dim3(kBlock), 0, st, s, fp, pb, iter, finalsOnly ? 1 : 0);
 }
 
 void launch_resolve_samples(hipStream_t st, const FrameParams& fp, const PathBuffers& pb) {
