@@ -52,6 +52,13 @@ constexpr int kBlock = 256;
 #define PT_TUNE_BLOCK 1024
 #endif
 constexpr int kTraceBlock = PT_TUNE_BLOCK;  // k_trace: 16 wavefronts per block, two blocks per CU (LDS: 2 x ~64 KB of 160 KB)
-constexpr int kTopNodes = 2032;   // nodes k_trace keeps in LDS (32 B each; with the shard prefix sums just under 64 KB)
+#ifndef PT_TUNE_TOP
+#define PT_TUNE_TOP 2032
+#endif
+#ifndef PT_TUNE_GRID
+#define PT_TUNE_GRID 512
+#endif
+constexpr int kTraceGrid = PT_TUNE_GRID;  // persistent grid of k_trace: blocks per CU x 256 CUs
+constexpr int kTopNodes = PT_TUNE_TOP;   // nodes k_trace keeps in LDS (32 B each; with the shard prefix sums just under 64 KB)
 
 }  // namespace ptd

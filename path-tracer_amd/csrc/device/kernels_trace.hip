@@ -376,7 +376,7 @@ static inline unsigned grid_for(size_t n) {
 static inline unsigned trace_grid(size_t nMax) {
     size_t g = (nMax + kTraceBlock - 1) / kTraceBlock;
     if (g < 1) g = 1;
-    if (g > 512) g = 512;
+    if (g > (size_t)kTraceGrid) g = kTraceGrid;
     return (unsigned)g;
 }
 void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,

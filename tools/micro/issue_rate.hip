@@ -1,0 +1,113 @@
+// Micro-benchmark (diagnostic, not part of the library): issue rate of vector and scalar instructions on one
+// gfx950 SIMD as a function of resident wavefronts.  Build: hipcc --offload-arch=gfx950 -O3 issue_rate.hip -o issue_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int MODE>
+__global__ void k(float* out, int iters, long long* cyc) {
+    float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f, a4 = 4.f, a5 = 5.f, a6 = 6.f, a7 = 7.f;
+    int s0 = iters, s1 = 1, s2 = 2, s3 = 3;
+    long long t0 = clock64();
+    for (int i = 0; i < iters; i++) {
+        if (MODE == 0) {  // 32 independent v_fma_f32
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n"
+                             "v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (MODE == 1) {  // 32 s_add_u32 (4 chains)
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
+                             : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)::"scc");
+        } else if (MODE == 2) {  // 16 v_fma + 16 s_add interleaved
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_fma_f32 %0, %0, %0, %0\n s_add_u32 %4, %4, 1\n v_fma_f32 %1, %1, %1, %1\n s_add_u32 %5, %5, 1\n"
+                             "v_fma_f32 %2, %2, %2, %2\n s_add_u32 %6, %6, 1\n v_fma_f32 %3, %3, %3, %3\n s_add_u32 %7, %7, 1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)::"scc");
+        } else if (MODE == 3) {  // 32 independent v_pk_fma_f32
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                asm volatile("v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+            a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x; a5 = p2.y; a6 = p3.x; a7 = p3.y;
+        } else if (MODE == 4) {  // 32 v_cndmask (VCC read)
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"vcc");
+        } else if (MODE == 6) {  // 32 v_cndmask on 8 independent registers
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                             "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(1.5f) : "vcc");
+        } else if (MODE == 7) {  // 32 v_fma_f32 in 4 chains (dependence distance 4)
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        } else if (MODE == 8) {  // 32 v_fma_f32 in ONE chain (fully dependent)
+#pragma unroll
+            for (int r = 0; r < 32; r++) asm volatile("v_fma_f32 %0, %0, %0, %0\n" : "+v"(a0));
+        } else if (MODE == 9) {  // 32 v_max3_f32, 8 independent
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %4\n v_max3_f32 %3, %3, %4, %5\n"
+                             "v_max3_f32 %4, %4, %5, %6\n v_max3_f32 %5, %5, %6, %7\n v_max3_f32 %6, %6, %7, %0\n v_max3_f32 %7, %7, %0, %1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (MODE == 10) {  // 32 v_cndmask_b32_e64 with an SGPR-pair mask, 8 independent
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n"
+                             "v_cndmask_b32_e64 %4, %4, %8, s[20:21]\n v_cndmask_b32_e64 %5, %5, %8, s[20:21]\n v_cndmask_b32_e64 %6, %6, %8, s[20:21]\n v_cndmask_b32_e64 %7, %7, %8, s[20:21]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(1.5f) : "s20", "s21");
+        } else if (MODE == 5) {  // 16 x (v_cmp + s_and_saveexec-like scalar mask op)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                asm volatile("v_cmp_gt_f32 vcc, %0, %1\n s_and_b64 vcc, vcc, exec\n" ::"v"(a0), "v"(a1) : "vcc", "scc");
+        }
+    }
+    long long t1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(s0 + s1 + s2 + s3);
+}
+
+template <int MODE>
+int run(const char* name, int instrPerIter) {
+    float* out; long long* cyc; long long h;
+    CHECK(hipMalloc(&out, 256 * 2048 * sizeof(float)));
+    CHECK(hipMalloc(&cyc, 8));
+    const int iters = 20000;
+    for (int wavesPerSimd : {1, 2, 4, 8}) {
+        const int threads = wavesPerSimd * 4 * 64;  // one block per CU
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads > 1024 ? 1024 : threads), 0, 0, out, 10, cyc);  // warm
+        const int blocks = threads > 1024 ? 256 * (threads / 1024) : 256;
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads > 1024 ? 1024 : threads), 0, 0, out, iters, cyc);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        CHECK(hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost));
+        // clock64 = s_memtime ticks (100 MHz realtime or shader clock depending on build): report wall-derived cycles at 2.4 GHz too
+        const double instrPerSimd = (double)iters * instrPerIter * wavesPerSimd;
+        printf("%-28s waves/SIMD %d: %.3f ms, %.2f ns per instr per SIMD (= %.2f cycles at 2.4 GHz), clock64 delta %lld\n", name,
+               wavesPerSimd, ms, ms * 1e6 / instrPerSimd, ms * 1e6 / instrPerSimd * 2.4, h);
+    }
+    hipFree(out); hipFree(cyc);
+    return 0;
+}
+int main() {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    if (run<0>("v_fma_f32 x32 (8 chains)", 32)) return 1;
+    if (run<7>("v_fma_f32 x32 (4 chains)", 32)) return 1;
+    if (run<8>("v_fma_f32 x32 (1 chain)", 32)) return 1;
+    if (run<9>("v_max3_f32 x32", 32)) return 1;
+    if (run<6>("v_cndmask vcc x32 (8 indep)", 32)) return 1;
+    if (run<10>("v_cndmask sgpr x32 (8 indep)", 32)) return 1;
+    return 0;
+}

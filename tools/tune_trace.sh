@@ -14,9 +14,10 @@ if [ "$1" = build ]; then
   while [ $# -ge 2 ]; do
     name=$1; defs=$2; shift 2
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src/device/kernels_trace.hip -o $out/kt_$name.o
+    /opt/rocm/bin/hipcc $FLAGS $defs -c $src/api/api_device.hip -o $out/api_$name.o   # kTopNodes is used on the host side too
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libmipt_$name.so $out/kt_$name.o $src/device/kernels_integrate.o \
-        $src/api/api_device.o $src/api/api_host.o $src/host/obj_loader.o $src/host/bvh_build.o $src/host/image_io.o -lz
-    rm -f $out/kt_$name.o
+        $out/api_$name.o $src/api/api_host.o $src/host/obj_loader.o $src/host/bvh_build.o $src/host/image_io.o -lz
+    rm -f $out/kt_$name.o $out/api_$name.o
     echo "built $name ($defs)"
   done
 elif [ "$1" = bench ]; then
