@@ -193,47 +193,47 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
             if (nEmpty == 64) continue;  // nothing else to do yet
         }
         // ---- box burst: walking lanes with room to park a leaf advance up to kBoxBurst nodes (cs488.h:1669-1680) ----
+        // The scalar unit (exec-mask juggling, ~4.4 cycles per instruction and SIMD) limits this loop as much as the
+        // vector ALU does (tools/micro/issue_rate.hip), so the step keeps its control flow flat: one region for the
+        // node load, one for a parked leaf, one for a finished ray; when every ray of the wavefront qualifies for the
+        // reciprocal slab test (the usual case) the burst runs a copy without the IEEE arm.
+#define PT_BOX_STEP(FASTONLY)                                                                                         \
+    if (walking && !PT_PEND_FULL()) {                                                                                 \
+        float4v n0, n1; /* {min.x, max.x, min.y, max.y} {min.z, max.z, idMiss, link} */                               \
+        if (node < nTop) { /* top of the tree: from LDS */                                                            \
+            n0 = topLds[2 * node];                                                                                    \
+            n1 = topLds[2 * node + 1];                                                                                \
+        } else {                                                                                                      \
+            n0 = nodesGlobal[2 * (size_t)node];                                                                       \
+            n1 = nodesGlobal[2 * (size_t)node + 1];                                                                   \
+        }                                                                                                             \
+        if (COUNT) nv++;                                                                                              \
+        bool hit;                                                                                                     \
+        if (FASTONLY) hit = slab_hit_fast(n0, n1, ox, oy, oz, dx, dy, dz, yx, yy, yz);                                \
+        else hit = fast ? slab_hit_fast(n0, n1, ox, oy, oz, dx, dy, dz, yx, yy, yz)                                   \
+                        : slab_hit_ieee(n0, n1, vec3{ox, oy, oz}, vec3{dx, dy, dz});                                  \
+        const int link = f2i(n1.w);                                                                                   \
+        const bool interior = link >= 0;                                                                              \
+        node = (hit && interior) ? link : f2i(n1.z); /* idHit of an interior node, else idMiss */                     \
+        if (hit && !interior) {                      /* leaf: park its triangles, go on at idHit (= idMiss) */        \
+            if (cur < 0) {                                                                                            \
+                cur = ~link;                                                                                          \
+            } else {                                                                                                  \
+                p2 = p1; p1 = p0; p0 = ~link;                                                                         \
+                ++nPend;                                                                                              \
+            }                                                                                                         \
+        }                                                                                                             \
+        walking = node != 0;                                                                                          \
+        if (!walking && cur < 0) PT_FINISH();                                                                         \
+    }
+        if (__ballot(hasRay && !fast) == 0ull) {
 #pragma unroll
-        for (int b = 0; b < kBoxBurst; b++) {
-            if (walking && !PT_PEND_FULL()) {
-                float4v n0, n1;  // {min.x, max.x, min.y, max.y} {min.z, max.z, idMiss, link}
-                if (node < nTop) {  // top of the tree: from LDS
-                    n0 = topLds[2 * node];
-                    n1 = topLds[2 * node + 1];
-                } else {
-                    n0 = nodesGlobal[2 * (size_t)node];
-                    n1 = nodesGlobal[2 * (size_t)node + 1];
-                }
-                if (COUNT) nv++;
-#ifdef PT_TUNE_DUMMY_VALU  // diagnostic builds only (tools/tune_trace.sh): extra independent vector instructions per box step
+            for (int b = 0; b < kBoxBurst; b++) PT_BOX_STEP(true)
+        } else {
 #pragma unroll
-                for (int dv = 0; dv < PT_TUNE_DUMMY_VALU; dv++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummyValu));
-#endif
-                const bool hit = fast ? slab_hit_fast(n0, n1, ox, oy, oz, dx, dy, dz, yx, yy, yz)
-                                      : slab_hit_ieee(n0, n1, vec3{ox, oy, oz}, vec3{dx, dy, dz});
-                // bookkeeping under nested ifs on purpose: the kernel is bound by vector-ALU issue slots, and the
-                // exec-mask juggling of the ifs runs on the scalar unit beside it (the select form measured slower)
-                int next = f2i(n1.z);  // idMiss
-                if (hit) {
-                    const int link = f2i(n1.w);
-                    if (link < 0) {  // leaf: park its triangles, go on at idHit (= idMiss)
-                        if (cur < 0) {
-                            cur = ~link;
-                        } else {
-                            p2 = p1; p1 = p0; p0 = ~link;
-                            ++nPend;
-                        }
-                    } else {
-                        next = link;
-                    }
-                }
-                node = next;
-                if (next == 0) {
-                    walking = false;
-                    if (cur < 0) PT_FINISH();
-                }
-            }
+            for (int b = 0; b < kBoxBurst; b++) PT_BOX_STEP(false)
         }
+#undef PT_BOX_STEP
         // ---- triangle steps: when enough lanes hold parked leaves, or nobody can walk on ----
         const unsigned long long mCanWalk = __ballot(walking && !PT_PEND_FULL());
         unsigned long long mPend = __ballot(cur >= 0);

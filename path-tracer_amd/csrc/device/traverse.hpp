@@ -111,7 +111,9 @@ __device__ __forceinline__ bool slab_hit_fast(const float4v n0, const float4v n1
                                      __builtin_fminf(qz.x, qz.y));
     const float t2 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(qx.x, qx.y), __builtin_fmaxf(qy.x, qy.y)),
                                      __builtin_fmaxf(qz.x, qz.y));
-    return !(t1 > t2) & !((t1 < 0.0f) & (t2 < 0.0f));
+    // !(t1 > t2) && !(t1 < 0 && t2 < 0) for finite t1, t2: when t1 <= t2 the second clause is just !(t2 < 0), so
+    // the whole predicate is max(t1, 0) <= t2 (a -0 compares like +0 on either side) -- one compare instead of three
+    return !(__builtin_fmaxf(t1, 0.0f) > t2);
 }
 
 // raytraceTriangle, cs488.h:782-812, on the precomputed edges a = p0-p1, b = p0-p2.

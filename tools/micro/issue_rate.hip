@@ -66,6 +66,47 @@ __global__ void k(float* out, int iters, long long* cyc) {
                 asm volatile("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n"
                              "v_cndmask_b32_e64 %4, %4, %8, s[20:21]\n v_cndmask_b32_e64 %5, %5, %8, s[20:21]\n v_cndmask_b32_e64 %6, %6, %8, s[20:21]\n v_cndmask_b32_e64 %7, %7, %8, s[20:21]\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(1.5f) : "s20", "s21");
+        } else if (MODE == 11) {  // v_mul_f32_e32 (VOP2), 8 independent
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_mul_f32 %0, %0, %0\n v_mul_f32 %1, %1, %1\n v_mul_f32 %2, %2, %2\n v_mul_f32 %3, %3, %3\n"
+                             "v_mul_f32 %4, %4, %4\n v_mul_f32 %5, %5, %5\n v_mul_f32 %6, %6, %6\n v_mul_f32 %7, %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (MODE == 12) {  // v_min_f32_e32
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_min_f32 %0, %0, %1\n v_min_f32 %1, %1, %2\n v_min_f32 %2, %2, %3\n v_min_f32 %3, %3, %4\n"
+                             "v_min_f32 %4, %4, %5\n v_min_f32 %5, %5, %6\n v_min_f32 %6, %6, %7\n v_min_f32 %7, %7, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (MODE == 13) {  // v_mov_b32
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n"
+                             "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (MODE == 14) {  // v_cmp_gt_f32_e32 (writes vcc) x32
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cmp_gt_f32 vcc, %1, %2\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %3, %0\n"
+                             ::"v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");
+        } else if (MODE == 15) {  // (v_cmp_gt_f32 vcc ; v_cndmask_b32 e32) x16
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32 %4, %4, %0, vcc\n v_cmp_gt_f32 vcc, %1, %2\n v_cndmask_b32 %5, %5, %1, vcc\n"
+                             "v_cmp_gt_f32 vcc, %2, %3\n v_cndmask_b32 %6, %6, %2, vcc\n v_cmp_gt_f32 vcc, %3, %0\n v_cndmask_b32 %7, %7, %3, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)::"vcc");
+        } else if (MODE == 16) {  // s_and_saveexec_b64 + s_or_b64 exec (mask juggling) x16 pairs
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                asm volatile("s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n" ::: "s20", "s21", "scc");
+        } else if (MODE == 17) {  // not-taken s_cbranch_execz + s_nop... x32
+#pragma unroll
+            for (int r = 0; r < 32; r++) asm volatile("s_cbranch_execz 0\n" :::);
+        } else if (MODE == 18) {  // v_cmp_gt_f32_e64 to an SGPR pair x32
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                asm volatile("v_cmp_gt_f32 s[20:21], %0, %1\n v_cmp_gt_f32 s[22:23], %1, %2\n v_cmp_gt_f32 s[24:25], %2, %3\n v_cmp_gt_f32 s[26:27], %3, %0\n"
+                             ::"v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
         } else if (MODE == 5) {  // 16 x (v_cmp + s_and_saveexec-like scalar mask op)
 #pragma unroll
             for (int r = 0; r < 16; r++)
@@ -101,13 +142,30 @@ int run(const char* name, int instrPerIter) {
     hipFree(out); hipFree(cyc);
     return 0;
 }
-int main() {
+#include <cstdlib>
+int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IOLBF, 0);
-    if (run<0>("v_fma_f32 x32 (8 chains)", 32)) return 1;
-    if (run<7>("v_fma_f32 x32 (4 chains)", 32)) return 1;
-    if (run<8>("v_fma_f32 x32 (1 chain)", 32)) return 1;
-    if (run<9>("v_max3_f32 x32", 32)) return 1;
-    if (run<6>("v_cndmask vcc x32 (8 indep)", 32)) return 1;
-    if (run<10>("v_cndmask sgpr x32 (8 indep)", 32)) return 1;
+    int which = argc > 1 ? atoi(argv[1]) : 0;
+    if (which == 0) {
+        if (run<0>("v_fma_f32 x32 (8 chains)", 32)) return 1;
+        if (run<7>("v_fma_f32 x32 (4 chains)", 32)) return 1;
+        if (run<8>("v_fma_f32 x32 (1 chain)", 32)) return 1;
+        if (run<3>("v_pk_fma_f32 x32", 32)) return 1;
+        if (run<9>("v_max3_f32 x32", 32)) return 1;
+        if (run<6>("v_cndmask vcc x32 (8 indep)", 32)) return 1;
+        if (run<10>("v_cndmask sgpr x32 (8 indep)", 32)) return 1;
+        if (run<1>("s_add_u32 x32", 32)) return 1;
+        if (run<2>("v_fma + s_add x16 each", 32)) return 1;
+        if (run<5>("v_cmp + s_and x16 each", 32)) return 1;
+    } else {
+        if (run<11>("v_mul_f32_e32 x32", 32)) return 1;
+        if (run<12>("v_min_f32_e32 x32", 32)) return 1;
+        if (run<13>("v_mov_b32 x32", 32)) return 1;
+        if (run<14>("v_cmp_gt_f32 vcc x32", 32)) return 1;
+        if (run<15>("v_cmp vcc + v_cndmask x16", 32)) return 1;
+        if (run<18>("v_cmp_gt_f32 sgpr x32", 32)) return 1;
+        if (run<16>("saveexec + or exec x16", 32)) return 1;
+        if (run<17>("s_cbranch_execz (not taken) x32", 32)) return 1;
+    }
     return 0;
 }

@@ -6,7 +6,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/path-tracer_amd/csrc
 out=$root/build_variants
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize"
 if [ "$1" = build ]; then
   shift
   mkdir -p $out
