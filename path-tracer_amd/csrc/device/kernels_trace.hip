@@ -102,12 +102,13 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
     bool hasRay = false;
     int node = 0;                     // next node to test; 0 after the walk has run off the tree (root is tested first)
     bool walking = false;             // the box walk of this ray is still going
-    // FIFO of leaves whose triangles are still to be tested, in visit order.  cur = next triangle of the oldest
-    // parked leaf (-1: none); p0..p2 = first triangles of the nPend younger ones, newest in p0.  The walk does
+    // FIFO of leaves whose triangles are still to be tested, in visit order.  slots = parked leaves (0..4); cur =
+    // next triangle of the oldest one (valid while slots > 0); p0..p2 = first triangles of the slots-1 younger
+    // ones, newest in p0.  The walk does
     // not depend on triangle results (the reference's box test ignores the current best hit, cs488.h:1669), so
     // parking the triangle tests changes nothing but the schedule; the tests themselves run per lane in visit
     // order, which keeps the strict-'<' tie-break.
-    int cur = -1, nPend = 0, p0 = 0, p1 = 0, p2 = 0;
+    int slots = 0, cur = 0, p0 = 0, p1 = 0, p2 = 0;
     unsigned raySlot = 0, queueSlot = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
     float tMin = 0.0f, tMax = 0.0f;
@@ -138,10 +139,9 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
         }                                                                                  \
         hasRay = false;                                                                    \
         walking = false;                                                                   \
-        cur = -1;                                                                          \
-        nPend = 0;                                                                         \
+        slots = 0;                                                                         \
     } while (0)
-#define PT_PEND_FULL() (cur >= 0 && nPend >= kDepth - 1)
+#define PT_PEND_FULL() (slots >= kDepth)
 
     while (true) {
         const unsigned long long mEmpty = __ballot(!hasRay);
@@ -213,18 +213,20 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
         else hit = fast ? slab_hit_fast(n0, n1, ox, oy, oz, dx, dy, dz, yx, yy, yz)                                   \
                         : slab_hit_ieee(n0, n1, vec3{ox, oy, oz}, vec3{dx, dy, dz});                                  \
         const int link = f2i(n1.w);                                                                                   \
-        const bool interior = link >= 0;                                                                              \
-        node = (hit && interior) ? link : f2i(n1.z); /* idHit of an interior node, else idMiss */                     \
-        if (hit && !interior) {                      /* leaf: park its triangles, go on at idHit (= idMiss) */        \
-            if (cur < 0) {                                                                                            \
+        const bool leafHit = hit && link < 0; /* park its triangles, go on at idHit (= idMiss) */                     \
+        const bool none = slots == 0;                                                                                 \
+        node = (!hit || leafHit) ? f2i(n1.z) : link; /* idMiss, or idHit of an interior node */                       \
+        if (leafHit) {                                                                                                \
+            if (none) {                                                                                               \
                 cur = ~link;                                                                                          \
             } else {                                                                                                  \
                 p2 = p1; p1 = p0; p0 = ~link;                                                                         \
-                ++nPend;                                                                                              \
             }                                                                                                         \
+            ++slots;                                                                                                  \
         }                                                                                                             \
-        walking = node != 0;                                                                                          \
-        if (!walking && cur < 0) PT_FINISH();                                                                         \
+        const bool ended = node == 0;                                                                                 \
+        walking = !ended;                                                                                             \
+        if (ended && none && !leafHit) PT_FINISH();                                                                   \
     }
         if (__ballot(hasRay && !fast) == 0ull) {
 #pragma unroll
@@ -236,10 +238,10 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
 #undef PT_BOX_STEP
         // ---- triangle steps: when enough lanes hold parked leaves, or nobody can walk on ----
         const unsigned long long mCanWalk = __ballot(walking && !PT_PEND_FULL());
-        unsigned long long mPend = __ballot(cur >= 0);
+        unsigned long long mPend = __ballot(slots > 0);
         if (mPend != 0ull && (__popcll(mPend) >= kLeafLanes || mCanWalk == 0ull)) {
             do {
-                if (cur >= 0) {  // one triangle of the oldest parked leaf (cs488.h:1671-1675 / 1693-1697)
+                if (slots > 0) {  // one triangle of the oldest parked leaf (cs488.h:1671-1675 / 1693-1697)
                     const float4 q0 = s.leafTris[3 * (size_t)cur];
                     const float4 q1 = s.leafTris[3 * (size_t)cur + 1];
                     const float4 q2 = s.leafTris[3 * (size_t)cur + 2];
@@ -253,18 +255,17 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                     if (ANYHIT && acc) {
                         PT_FINISH();  // isHit returns at the first accepted triangle (cs488.h:1696)
                     } else if (f2i(q1.w)) {  // last triangle of this leaf: on to the next parked leaf
-                        if (nPend > 0) {
-                            cur = (nPend == 1) ? p0 : (nPend == 2) ? p1 : p2;
-                            --nPend;
-                        } else {
-                            cur = -1;
-                            if (!walking) PT_FINISH();
+                        --slots;
+                        if (slots > 0) {
+                            cur = (slots == 1) ? p0 : (slots == 2) ? p1 : p2;
+                        } else if (!walking) {
+                            PT_FINISH();
                         }
                     } else {
                         ++cur;
                     }
                 }
-                mPend = __ballot(cur >= 0);
+                mPend = __ballot(slots > 0);
             } while (__popcll(mPend) >= kLeafLanesKeep);
         }
     }
