@@ -46,6 +46,9 @@ namespace ptd {
 #ifndef PT_TUNE_LEAF_KEEP
 #define PT_TUNE_LEAF_KEEP 16
 #endif
+#ifndef PT_TUNE_STUCK
+#define PT_TUNE_STUCK 8
+#endif
 #ifndef PT_TUNE_BURST
 #define PT_TUNE_BURST 4
 #endif
@@ -59,6 +62,7 @@ namespace ptd {
 #define PT_TUNE_LEAF_KEEP_ANYHIT PT_TUNE_LEAF_KEEP
 #endif
 constexpr int kRefillLanes = PT_TUNE_REFILL;  // refill when this many lanes are empty
+constexpr int kStuckLanes = PT_TUNE_STUCK;    // ... or when this many lanes cannot walk on before their triangles are tested
 constexpr int kBoxBurst = PT_TUNE_BURST;      // box steps between two votes
 constexpr int kPendClosest = 4;               // leaves a lane may park before it must wait (closest hit)
 constexpr int kPendAnyHit = PT_TUNE_PEND_ANYHIT;  // any-hit rays end at their first accepted triangle: parking more wastes box steps
@@ -239,7 +243,9 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
         // ---- triangle steps: when enough lanes hold parked leaves, or nobody can walk on ----
         const unsigned long long mCanWalk = __ballot(walking && !PT_PEND_FULL());
         unsigned long long mPend = __ballot(slots > 0);
-        if (mPend != 0ull && (__popcll(mPend) >= kLeafLanes || mCanWalk == 0ull)) {
+        // lanes that cannot walk on before their parked triangles are tested (walk over, or FIFO full)
+        const unsigned long long mStuck = mPend & ~mCanWalk;
+        if (mPend != 0ull && (__popcll(mPend) >= kLeafLanes || __popcll(mStuck) >= kStuckLanes || mCanWalk == 0ull)) {
             do {
                 if (slots > 0) {  // one triangle of the oldest parked leaf (cs488.h:1671-1675 / 1693-1697)
                     const float4 q0 = s.leafTris[3 * (size_t)cur];
