@@ -1,0 +1,107 @@
+"""BASELINE.json configs 2-5 at their FULL resolution, sample counts and bounce caps (config 1, primary ids at
+512x512, is tests/test_gpu_trace.py::test_full_size_properties).  The GPU renders the whole frame through the
+C-ABI; the CPU oracle, which needs seconds per megapixel-sample, re-renders a subsample of rows with the same
+counter RNG and is compared at the tolerances of tests/test_gpu_render.py.  Size-independent properties cover the
+rest: finiteness, progressive == one-shot (bitwise), Monte-Carlo convergence ~ 1/sqrt(spp).
+Stand-ins as everywhere: sponza-standin for the absent sponza.obj, a procedural probe for uffizi_probe.hdr."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_cache = {}
+
+
+def setup_scene(B, sf, name):
+    if name not in _cache:
+        arrays = sf.sponza_standin(1) if name == "sponza" else sf.load_scene_arrays(name)
+        env = sf.procedural_env(256)
+        lights = sf.SPONZA_LIGHT if name == "sponza" else sf.DEFAULT_LIGHT
+        scene = sf.product_scene_from_mesh_arrays(*arrays, env=env, lights=lights)
+        _cache[name] = (B.Context(scene, device=0), sf.oracle_scene_from_mesh_arrays(*arrays, env=env, lights=lights))
+    return _cache[name]
+
+
+def cams(B, ob, sf, name, w, h):
+    if name == "sponza":
+        return B.make_camera(w, h, sf.SPONZA_EYE, sf.SPONZA_LOOKAT), ob.make_camera(w, h, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
+    return B.default_camera(w, h), ob.make_camera(w, h)
+
+
+def compare_rows(img, rows, oracle_rows, rmse_tol, mean_tol):
+    got = np.stack([img[r] for r in rows]).astype(np.float64)
+    ref = np.stack(oracle_rows).astype(np.float64)
+    mean = ref.mean()
+    assert mean > 0
+    rmse = np.sqrt(np.mean((got - ref) ** 2))
+    assert rmse <= rmse_tol * mean, (rmse / mean, "relative RMSE over the sampled rows")
+    assert abs(got.mean() - mean) <= mean_tol * mean, (abs(got.mean() - mean) / mean, "relative mean difference")
+
+
+def test_config2_bunny_1024_direct(B, ob, sf):
+    """configs[1]: bunny.obj 1024x1024, Scene::Raytrace + shade with the environment on misses"""
+    ctx, orc = setup_scene(B, sf, "bunny")
+    cam, ocam = cams(B, ob, sf, "bunny", 1024, 1024)
+    img = ctx.render(cam, mode=B.MODE_DIRECT)
+    assert np.isfinite(img).all()
+    rows = list(range(5, 1024, 64))
+    compare_rows(img, rows, [orc.raytrace(ocam, rows=(r, r + 1))[r] for r in rows], 1e-5, 1e-6)
+
+
+def test_config3_teapot_glass_1080p_path_64spp_8_bounces(B, ob, sf):
+    """configs[2]: teapot-glass.obj 1920x1080, 64 spp, 8 bounces, seed 1 (refraction, total internal reflection,
+    environment lookups)"""
+    ctx, orc = setup_scene(B, sf, "teapot-glass")
+    cam, ocam = cams(B, ob, sf, "teapot-glass", 1920, 1080)
+    img = ctx.render(cam, mode=B.MODE_PATH, spp=64, max_bounces=8, seed=1)
+    assert np.isfinite(img).all()
+    rows = [300, 480, 540, 600, 700]
+    ref = [orc.pathtrace(ocam, spp=64, max_bounces=8, rng_mode=1, seed=1, rows=(r, r + 1))[r] for r in rows]
+    compare_rows(img, rows, ref, 5e-3, 1e-4)
+
+
+def test_config4_sponza_1080p_path_16spp_4_bounces(B, ob, sf):
+    """configs[3], the bench workload: sponza-standin 1920x1080, 16 spp, 4 bounces, seed 1; also the two-partition
+    split of the same frame (what 2 GPUs render) is bit-identical"""
+    ctx, orc = setup_scene(B, sf, "sponza")
+    cam, ocam = cams(B, ob, sf, "sponza", 1920, 1080)
+    img = ctx.render(cam, mode=B.MODE_PATH, spp=16, max_bounces=4, seed=1)
+    assert np.isfinite(img).all()
+    rows = [40, 333, 540, 777, 1000]
+    ref = [orc.pathtrace(ocam, spp=16, max_bounces=4, rng_mode=1, seed=1, rows=(r, r + 1))[r] for r in rows]
+    compare_rows(img, rows, ref, 5e-3, 1e-4)
+    halves = sum(ctx.render(cam, mode=B.MODE_PATH, spp=16, max_bounces=4, seed=1, part_index=k, part_count=2, tile_w=64,
+                            tile_h=8) for k in range(2))
+    assert np.array_equal(halves.view(np.uint32), img.view(np.uint32))
+
+
+def test_config5_4k_progressive(B, ob, sf):
+    """configs[4]: sponza-standin 3840x2160 progressive path tracing, 4 bounces, seed 1.  The config's 1024 spp is
+    cut to 16 here (the suite must stay short; throughput does not depend on the sample index): the frame rendered
+    progressively in batches of 4 samples equals the one-shot 16-spp frame bit for bit, sampled rows match the
+    oracle, and the error against the 16-spp frame falls like 1/sqrt(spp)"""
+    ctx, orc = setup_scene(B, sf, "sponza")
+    w, h = 3840, 2160
+    cam, ocam = cams(B, ob, sf, "sponza", w, h)
+    nbytes = w * h * 3 * 4
+    acc, rgb = ctx.buffer_alloc(nbytes), ctx.buffer_alloc(nbytes)
+    frames = {}
+    for off in range(0, 16, 4):
+        ctx.render_device(cam, B.RenderParams(B.MODE_PATH, 4, off, 4, 1, 0, 1, 0, 0), acc, rgb)
+        if off + 4 in (4, 16):
+            frames[off + 4] = ctx.buffer_download(rgb, (h, w, 3))
+    ctx.buffer_free(acc)
+    ctx.buffer_free(rgb)
+    one = ctx.render(cam, mode=B.MODE_PATH, spp=16, max_bounces=4, seed=1)
+    assert np.isfinite(one).all()
+    assert np.array_equal(frames[16].view(np.uint32), one.view(np.uint32))
+    rows = [700, 1500]
+    ref = [orc.pathtrace(ocam, spp=16, max_bounces=4, rng_mode=1, seed=1, rows=(r, r + 1))[r] for r in rows]
+    compare_rows(one, rows, ref, 5e-3, 1e-4)
+    # convergence: 1-spp and 4-spp frames against the 16-spp frame; independent samples => error ratio ~ sqrt(4) = 2
+    # (the 16-spp frame contains the same samples, which shifts the ratio to sqrt((1-1/16)/(1/4-1/16)) = 2.24)
+    one_spp = ctx.render(cam, mode=B.MODE_PATH, spp=1, max_bounces=4, seed=1)
+    lit = one.sum(axis=2) > 0
+    e1 = np.sqrt(np.mean((one_spp[lit].astype(np.float64) - one[lit]) ** 2))
+    e4 = np.sqrt(np.mean((frames[4][lit].astype(np.float64) - one[lit]) ** 2))
+    assert 1.8 < e1 / e4 < 2.7, (e1, e4)
