@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
     float dummyValu = 0.5f;
 #endif
     // wavefront-uniform chunk of ray indices
-    unsigned chunkBase = 0, chunkLeft = 0;
+    unsigned chunkBase = 0, chunkLeft = 0, chunkShard = 0;
     bool exhausted = (total == 0);
     constexpr int kDepth = ANYHIT ? kPendAnyHit : kPendClosest;  // leaves a lane may park (1..4)
     // triangle steps start when this many lanes hold parked leaves and go on while kLeafLanesKeep still do
@@ -162,6 +162,9 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                 } else {
                     chunkBase = base;
                     chunkLeft = (total - base) < 64u ? (total - base) : 64u;
+                    // shard of the chunk's first ray: the number of shards that end at or before it (one vote
+                    // instead of a binary search per lane; lanes step on from here, usually zero times)
+                    if (q.counts) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= base));
                 }
             }
             if (chunkLeft != 0) {
@@ -170,13 +173,10 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                 if (!hasRay && rank < take) {
                     const unsigned j = chunkBase + rank;  // dense ray index
                     unsigned slot = j;
-                    if (q.counts) {  // dense index -> shard by binary search over the prefix sums
-                        unsigned lo = 0, hi = kShards;
-                        while (hi - lo > 1) {
-                            const unsigned mid = (lo + hi) >> 1;
-                            if (prefix[mid] <= j) lo = mid; else hi = mid;
-                        }
-                        slot = lo * q.regionSize + (j - prefix[lo]);
+                    if (q.counts) {  // dense index -> shard: j < total = prefix[kShards] ends the loop
+                        unsigned sh = chunkShard;
+                        while (j >= prefix[sh + 1]) ++sh;
+                        slot = sh * q.regionSize + (j - prefix[sh]);
                     }
                     queueSlot = slot;
                     raySlot = index ? (unsigned)index[slot] : slot;
