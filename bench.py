@@ -173,11 +173,12 @@ def main():
         ko = kernel_line(st["rays_occluded"], cnt["node_visits_occluded"], cnt["tri_tests_occluded"], st["ms_occluded"],
                          st["launches_occluded"])
         dom, dom_name = (kc, "k_trace_closest") if st["ms_closest"] >= st["ms_occluded"] else (ko, "k_trace_occluded")
-        traffic = None
+        traffic, valu_frac, l2_hit = None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(dom_name, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tf)).get(dom_name, {})
+                traffic, valu_frac, l2_hit = rec.get("hbm_bytes_per_launch"), rec.get("valu_active_frac"), rec.get("l2_hit_rate")
             except Exception:
                 traffic = None
         out = {
@@ -198,9 +199,33 @@ def main():
                          "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom_name,
                          "per_kernel": {"k_trace_closest": kc, "k_trace_occluded": ko,
                                         "other_ms_total": st["ms_other"], "other_launches": int(st["launches_other"])},
+                         "valu_active_frac": valu_frac, "l2_hit_rate": l2_hit,
                          "note": "achieved = algorithmic bytes (48 B/ray + 32 B/node visit + 36 B/triangle test) per "
-                                 "launch / average launch duration from HIP events in the timed region (rank 0)"},
+                                 "launch / average launch duration from HIP events in the timed region (rank 0). The walk "
+                                 "re-reads a few MB of nodes from LDS/L1/L2, so algorithmic bytes exceed HBM traffic "
+                                 "(`traffic`, PMC) about tenfold and frac can exceed 1: the kernel is bound by vector-ALU "
+                                 "issue (valu_active_frac, PMC), not by HBM"},
         }
+        if world == 1:
+            # primary-only rate of configs[0] (cornellbox 512x512, closest-hit ids), reported beside the
+            # headline; 262,144 rays per frame cannot fill the chip, this is a latency figure
+            try:
+                cb = sf.product_scene_from_mesh_arrays(*sf.load_scene_arrays("cornellbox"))
+                cctx = B.Context(cb, device=local_rank, stream=stream.cuda_stream)
+                ccam = B.default_camera(512, 512)
+                cbuf = torch.zeros(512 * 512 * 3, dtype=torch.float32, device=dev)
+                pp = B.RenderParams(B.MODE_PRIMARY, 1, 0, 0, SEED, 0, 1, TILE_W, TILE_H)
+                for _ in range(3):
+                    cctx.render_device(cam=ccam, params=pp, accum_ptr=0, rgb_ptr=cbuf.data_ptr())
+                torch.cuda.synchronize(dev)
+                tp = time.perf_counter()
+                for _ in range(50):
+                    cctx.render_device(cam=ccam, params=pp, accum_ptr=0, rgb_ptr=cbuf.data_ptr())
+                torch.cuda.synchronize(dev)
+                out["config"]["primary_only_cornellbox_512_mrays_s"] = 50 * 512 * 512 / (time.perf_counter() - tp) / 1e6
+            except Exception as e:  # informational only
+                out["config"]["primary_only_cornellbox_512_mrays_s"] = None
+                out["config"]["primary_only_error"] = str(e)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(arrays, env, sf.SPONZA_LIGHT, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
         print(json.dumps(out), flush=True)

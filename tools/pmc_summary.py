@@ -59,4 +59,9 @@ if "--traffic" in sys.argv:
             t[k] = {"hbm_bytes_per_launch": out[k]["hbm_read_bytes_per_launch"] + out[k].get("hbm_write_bytes_per_launch", 0.0),
                     "source": f"profiles/{rnd}/pmc_{tag}.json: 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes of "
                               "bench.py --steps 2 --warmup 1, averaged over that kernel's launches"}
+            if out[k].get("SQ_ACTIVE_INST_VALU") and out[k].get("GRBM_GUI_ACTIVE"):
+                # vector-ALU issue: quad-cycles in which a wavefront issued a VALU instruction, per SIMD (1024 on the
+                # chip), over the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                t[k]["valu_active_frac"] = (out[k]["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (out[k]["GRBM_GUI_ACTIVE"] / 8.0)
+                t[k]["l2_hit_rate"] = out[k].get("l2_hit_rate")
     json.dump(t, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
