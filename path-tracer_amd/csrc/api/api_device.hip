@@ -46,7 +46,99 @@ struct mipt_scene {
     int nNodes = 0, nLeafTris = 0, nTris = 0, nMaterials = 0, envW = 0, envH = 0, nLights = 0;
     bool planesTame = true;  // see DevScene::planesTame
     int nTopNodes = 0;       // see DevScene::nTopNodes
+    // 4-wide tree over the same leaves for the order-free traversal (device_scene.hpp "wide")
+    std::vector<float4> wnodes, leafBox;
+    int nWide = 0;
+    bool wideOk = false;
 };
+
+// Builds the 4-wide node array from the threaded binary tree: a wide node stands for a binary interior node, its (up
+// to 4) slots are that node's grandchildren, a child that is a leaf taking one slot itself.  Wide nodes are numbered
+// breadth-first, so the interior children of a node are consecutive (childBase + ordinal) and the top levels come
+// first (they are the ones k_trace_wide keeps in LDS); the leaves get ids of our own, again consecutive per wide
+// node (leafBase + ordinal).  Returns false, leaving the scene on the literal walk, when the input is not the
+// properly nested binary tree the order-free traversal relies on (see kernels_trace.hip) or exceeds its limits.
+static bool build_wide(const mipt_scene_desc* d, mipt_scene* s) {
+    const int n = d->n_nodes;
+    if (!s->planesTame) return false;
+    auto isLeaf = [&](int i) { return d->leaf_count[i] > 0; };
+    std::vector<int> left((size_t)n, -1), right((size_t)n, -1);
+    std::vector<char> seen((size_t)n, 0);
+    seen[0] = 1;
+    for (int i = 0; i < n; i++) {
+        if (isLeaf(i)) continue;
+        const int l = d->id_hit[i];
+        if (!(l > i && l < n)) return false;
+        const int r = d->id_miss[l];
+        if (!(r > l && r < n)) return false;
+        if (seen[l] || seen[r]) return false;  // every node has exactly one parent
+        seen[l] = seen[r] = 1;
+        left[i] = l; right[i] = r;
+        for (const int c : {l, r})
+            for (int a = 0; a < 3; a++)  // exact nesting: the child's box lies inside the parent's
+                if (!(d->node_min[3 * i + a] <= d->node_min[3 * c + a] && d->node_max[3 * c + a] <= d->node_max[3 * i + a])) return false;
+    }
+    for (int i = 0; i < n; i++)
+        if (!seen[i]) return false;
+    struct W { int bnode, depth; };
+    std::vector<W> wide;  // breadth-first
+    std::vector<int> slotsOf;  // 4 per wide node: binary node of the slot or -1
+    wide.push_back({0, 0});
+    int nLeaves = 0;
+    for (size_t w = 0; w < wide.size(); w++) {
+        const int b = wide[w].bnode;
+        int sl[4] = {-1, -1, -1, -1}, ns = 0;
+        if (isLeaf(b)) {
+            sl[ns++] = b;  // a tree that is one leaf: the root wide node has that leaf as its only slot
+        } else {
+            for (const int c : {left[b], right[b]}) {
+                if (isLeaf(c)) sl[ns++] = c;
+                else { sl[ns++] = left[c]; sl[ns++] = right[c]; }
+            }
+        }
+        for (int k = 0; k < 4; k++) {
+            slotsOf.push_back(sl[k]);
+            if (sl[k] >= 0 && !isLeaf(sl[k])) wide.push_back({sl[k], wide[w].depth + 1});
+        }
+        if (wide[w].depth >= ptd::kWideMaxDepth) return false;
+        if (wide.size() >= ((size_t)1 << 22)) return false;
+    }
+    const int nw = (int)wide.size();
+    s->wnodes.assign((size_t)ptd::kWideNodeF4 * nw, make_float4(0, 0, 0, 0));
+    // second pass: records (children of wide node w start at childBase, in the order the first pass appended them)
+    int nextChild = 1;
+    for (int w = 0; w < nw; w++) {
+        const int* sl = &slotsOf[(size_t)4 * w];
+        int interiorMask = 0, leafMask = 0, childBase = nextChild, leafBase = nLeaves;
+        float lo[3][4], hi[3][4];
+        for (int k = 0; k < 4; k++) {
+            const int src = sl[k] >= 0 ? sl[k] : sl[0];  // an empty slot repeats slot 0's (tame) box; the masks leave it out
+            for (int a = 0; a < 3; a++) { lo[a][k] = d->node_min[3 * src + a]; hi[a][k] = d->node_max[3 * src + a]; }
+            if (sl[k] < 0) continue;
+            if (isLeaf(sl[k])) {
+                leafMask |= 1 << k;
+                const int b = sl[k];
+                s->leafBox.push_back(make_float4(d->node_min[3 * b], d->node_max[3 * b], d->node_min[3 * b + 1], d->node_max[3 * b + 1]));
+                s->leafBox.push_back(make_float4(d->node_min[3 * b + 2], d->node_max[3 * b + 2],
+                                                 __builtin_bit_cast(float, d->leaf_first[b]), 0.0f));
+                nLeaves++;
+            } else {
+                interiorMask |= 1 << k;
+                nextChild++;
+            }
+        }
+        float4* rec = &s->wnodes[(size_t)ptd::kWideNodeF4 * w];
+        for (int a = 0; a < 3; a++) {
+            rec[2 * a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+            rec[2 * a + 1] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+        }
+        rec[6] = make_float4(__builtin_bit_cast(float, childBase), __builtin_bit_cast(float, leafBase),
+                             __builtin_bit_cast(float, interiorMask | (leafMask << 4)), 0.0f);
+    }
+    if (nextChild != nw) return false;
+    s->nWide = nw;
+    return true;
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -81,6 +173,8 @@ struct mipt_ctx {
     DevScene ds{};
     // scratch of the host-pointer entry points
     DevBuf sRays, sHits, sOut, sAux, sAux2;
+    DevBuf slow;           // rays the wide kernel handed back (trace_closest / trace_occluded)
+    bool useWide = true;   // MIPT_TRAVERSAL=walk in the environment forces the literal walk (A/B runs)
     // integrator state
     DevBuf pathMem, tileMem, frameMem;
     PathBuffers pb{};
@@ -135,7 +229,15 @@ void count_launch(mipt_ctx* c, int cls) {
     else c->acc.launches_other++;
 }
 
-// cursor == nullptr: use (and zero) the context's own cursor word
+// cursor == nullptr: use (and zero) the context's own cursor word.
+// Scenes that qualify (DevScene::nWide) go through the wide kernel first; it hands back the rays it may not take
+// (direction components that are zero, denormal, non-finite ...) in c->slow, and the literal walk traces those.
+// c->slow: [0] count, [1] cursor of the second launch, [2..] queue slots.
+int ensure_slow(mipt_ctx* c, size_t capacity) {
+    int rc = c->slow.ensure((capacity + 2) * sizeof(int));
+    if (rc == MIPT_OK) (void)hipMemsetAsync(c->slow.p, 0, 8, c->stream);
+    return rc;
+}
 void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, unsigned* cursor, float4* hits) {
     if (!cursor) {
         cursor = (unsigned*)(c->dTotals + 6);
@@ -143,7 +245,14 @@ void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView 
     }
     Timer t(c, 0);
     count_launch(c, 0);
-    launch_trace_closest(c->stream, c->ds, rays, index, q, cursor, hits, c->counting ? c->dTotals + 2 : nullptr);
+    unsigned long long* cnt = c->counting ? c->dTotals + 2 : nullptr;
+    if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
+        unsigned* sl = (unsigned*)c->slow.p;
+        launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, sl, (int*)(sl + 2));
+        launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, sl + 1, hits, cnt, (const int*)(sl + 2), sl);
+    } else {
+        launch_trace_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt);
+    }
 }
 void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueView q, unsigned* cursor, unsigned char* occ) {
     if (!cursor) {
@@ -152,7 +261,14 @@ void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueVie
     }
     Timer t(c, 1);
     count_launch(c, 1);
-    launch_trace_occluded(c->stream, c->ds, rays, target, q, cursor, occ, c->counting ? c->dTotals + 4 : nullptr);
+    unsigned long long* cnt = c->counting ? c->dTotals + 4 : nullptr;
+    if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
+        unsigned* sl = (unsigned*)c->slow.p;
+        launch_trace_wide_occluded(c->stream, c->ds, rays, target, q, cursor, occ, cnt, sl, (int*)(sl + 2));
+        launch_trace_occluded(c->stream, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, sl + 1, occ, cnt, (const int*)(sl + 2), sl);
+    } else {
+        launch_trace_occluded(c->stream, c->ds, rays, target, q, cursor, occ, cnt);
+    }
 }
 QueueView dense(size_t n) { return QueueView{nullptr, 0u, (unsigned)n}; }
 
@@ -270,6 +386,8 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         }
         for (char cv : covered)
             if (!cv) { delete s; return fail(MIPT_ERR_INVALID, "tri_index entry not owned by any leaf"); }
+        s->wideOk = build_wide(d, s);
+        if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->nWide = 0; }
         // textures -> one byte pool
         std::vector<int> texOfs((size_t)d->n_textures, 0);
         for (int i = 0; i < d->n_textures; i++) {
@@ -329,6 +447,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     HIP_TRY(hipSetDevice(device));
     mipt_ctx* c = new mipt_ctx();
     c->device = device;
+    if (const char* tv = getenv("MIPT_TRAVERSAL")) c->useWide = std::string(tv) != "walk";
     if (stream) c->stream = (hipStream_t)stream;
     else {
         if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(MIPT_ERR_DEVICE, "hipStreamCreate failed"); }
@@ -342,7 +461,9 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t szTex = align256(s->texels.size() + 4);
     const size_t szEnv = align256(s->env.size() * sizeof(float) + 4);
     const size_t szLights = align256(s->lights.size() * sizeof(float4) + 16);
-    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights;
+    const size_t szWide = align256(s->wnodes.size() * sizeof(float4) + 16);
+    const size_t szLeafBox = align256(s->leafBox.size() * sizeof(float4) + 16);
+    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights + szWide + szLeafBox;
     std::vector<unsigned char> stage(total, 0);
     size_t o = 0;
     const size_t oNodes = o; memcpy(&stage[o], s->nodes.data(), s->nodes.size() * sizeof(float4)); o += szNodes;
@@ -351,7 +472,9 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t oMat = o; memcpy(&stage[o], s->materials.data(), s->materials.size() * sizeof(float4)); o += szMat;
     const size_t oTex = o; if (!s->texels.empty()) memcpy(&stage[o], s->texels.data(), s->texels.size()); o += szTex;
     const size_t oEnv = o; if (!s->env.empty()) memcpy(&stage[o], s->env.data(), s->env.size() * sizeof(float)); o += szEnv;
-    const size_t oLights = o; if (!s->lights.empty()) memcpy(&stage[o], s->lights.data(), s->lights.size() * sizeof(float4));
+    const size_t oLights = o; if (!s->lights.empty()) memcpy(&stage[o], s->lights.data(), s->lights.size() * sizeof(float4)); o += szLights;
+    const size_t oWide = o; if (!s->wnodes.empty()) memcpy(&stage[o], s->wnodes.data(), s->wnodes.size() * sizeof(float4)); o += szWide;
+    const size_t oLeafBox = o; if (!s->leafBox.empty()) memcpy(&stage[o], s->leafBox.data(), s->leafBox.size() * sizeof(float4));
     if (hipMalloc(&c->arena, total) != hipSuccess) { mipt_context_destroy(c); return fail(MIPT_ERR_DEVICE, "hipMalloc(arena) failed"); }
     c->arenaBytes = total;
     if (hipMemcpy(c->arena, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
@@ -370,6 +493,10 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.envW = s->envW; c->ds.envH = s->envH; c->ds.nLights = s->nLights;
     c->ds.planesTame = s->planesTame ? 1 : 0;
     c->ds.nTopNodes = s->nTopNodes;
+    c->ds.wnodes = (const float4*)(base + oWide);
+    c->ds.leafBox = (const float4*)(base + oLeafBox);
+    c->ds.nWide = s->wideOk ? s->nWide : 0;
+    c->ds.nWideTop = s->nWide < ptd::kWideTopNodes ? s->nWide : ptd::kWideTopNodes;
     if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->dTotals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         mipt_context_destroy(c);
@@ -385,7 +512,7 @@ void mipt_context_destroy(mipt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : c->freeEvents) (void)hipEventDestroy(e);
-    c->sRays.release(); c->sHits.release(); c->sOut.release(); c->sAux.release(); c->sAux2.release();
+    c->slow.release(); c->sRays.release(); c->sHits.release(); c->sOut.release(); c->sAux.release(); c->sAux2.release();
     c->pathMem.release(); c->tileMem.release(); c->frameMem.release();
     if (c->dTotals) (void)hipFree(c->dTotals);
     if (c->arena) (void)hipFree(c->arena);

@@ -10,6 +10,15 @@
 //             (threaded links of StacklessBVH, reference cs488.h:1637-1659; 0 = done)
 //             Device numbering: the root is 0, the kTopNodes nodes with the largest boxes (a connected
 //             top of the tree) come first, the rest follow in preorder; the links are renumbered to match.
+//   wnodes    "wide": 7 x float4 per 4-wide node (112 B) over the SAME leaves, for rays that qualify for the
+//             order-free traversal (kernels_trace.hip: k_trace_wide); built on the host from the binary tree
+//             (api_device.hip: build_wide), numbered breadth-first:
+//               {min.x of slots 0..3} {max.x} {min.y} {max.y} {min.z} {max.z}
+//               {bits(childBase), bits(leafBase), bits(interiorMask | leafMask << 4), 0}
+//             interior child of slot k = childBase + popcount(interiorMask & ((1 << k) - 1)),
+//             leaf of slot k = leafBase + popcount(leafMask & ((1 << k) - 1))
+//   leafBox   2 x float4 per leaf (wide leaf numbering): {min.x, max.x, min.y, max.y} {min.z, max.z, bits(first
+//             leaf triangle), 0} -- the leaf's exact box, tested with the reference's exact predicate
 //   leafTris  3 x float4 per triangle reference (48 B), in leaf (triList) order:
 //               {p0.xyz, bits(original triangle id)}
 //               {p0-p1,  bits(1 if last triangle of its leaf)}
@@ -40,6 +49,9 @@ struct DevScene {
     const float* env;
     const float4* lights;
     int nNodes, nLeafTris, nTris, nMaterials, envW, envH, nLights;
+    const float4* wnodes;   // 4-wide nodes (nWide == 0: the scene does not qualify, every ray takes the literal walk)
+    const float4* leafBox;
+    int nWide, nWideTop;    // wide nodes [0, nWideTop) are kept in LDS by k_trace_wide
     int nTopNodes;   // nodes [0, nTopNodes) are the top of the tree, numbered first so that k_trace can hold them in LDS
     int planesTame;  // every box plane is 0 or has magnitude in [2^-61, 2^40] and min <= max: the exact reciprocal slab division may be used (traverse.hpp)
 };
@@ -58,6 +70,17 @@ constexpr int kTraceBlock = PT_TUNE_BLOCK;  // k_trace: 16 wavefronts per block,
 #ifndef PT_TUNE_GRID
 #define PT_TUNE_GRID 512
 #endif
+constexpr int kWideNodeF4 = 7;      // float4 per wide node
+constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's per-lane stack can hold (binary depth 32)
+#ifndef PT_TUNE_WIDE_BLOCK
+#define PT_TUNE_WIDE_BLOCK 512
+#endif
+// LDS of one k_trace_wide block (two blocks per CU, 80 KB each): the per-lane stacks (kWideMaxDepth words per lane),
+// the shard prefix sums, and the first kWideTopNodes wide nodes (112 B each)
+#ifndef PT_TUNE_WIDE_TOP
+#define PT_TUNE_WIDE_TOP ((81920 - 320 - 4 * kWideMaxDepth * PT_TUNE_WIDE_BLOCK) / 112)
+#endif
+constexpr int kWideTopNodes = PT_TUNE_WIDE_TOP;
 constexpr int kTraceGrid = PT_TUNE_GRID;  // persistent grid of k_trace: blocks per CU x 256 CUs
 constexpr int kTopNodes = PT_TUNE_TOP;   // nodes k_trace keeps in LDS (32 B each; with the shard prefix sums just under 64 KB)
 

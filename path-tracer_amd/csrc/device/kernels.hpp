@@ -78,10 +78,21 @@ struct FrameParams {
 };
 
 // cursor: one zeroed word per launch (the work counter the persistent wavefronts pull ray chunks from)
+// literal threaded walk (kernels_trace.hip).  remap != nullptr: trace only the queue slots remap[0 .. *remapCount)
 void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
-                          unsigned* cursor, float4* hits, unsigned long long* counters);
+                          unsigned* cursor, float4* hits, unsigned long long* counters, const int* remap = nullptr,
+                          const unsigned* remapCount = nullptr);
 void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
-                           unsigned* cursor, unsigned char* occ, unsigned long long* counters);
+                           unsigned* cursor, unsigned char* occ, unsigned long long* counters, const int* remap = nullptr,
+                           const unsigned* remapCount = nullptr);
+// order-free traversal over the 4-wide tree (kernels_trace_wide.hip) for the rays that qualify; the queue slots of
+// the others are appended to slowList (count in *slowCount) for a literal walk afterwards
+void launch_trace_wide_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
+                               unsigned* cursor, float4* hits, unsigned long long* counters, unsigned* slowCount,
+                               int* slowList);
+void launch_trace_wide_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
+                                unsigned* cursor, unsigned char* occ, unsigned long long* counters, unsigned* slowCount,
+                                int* slowList);
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays);
 void launch_resolve_hits(hipStream_t st, const DevScene& s, const float4* rays, const float4* hits, size_t n,
                          float* out);

@@ -78,7 +78,11 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                                                   const int* __restrict__ index, const int* __restrict__ target,
                                                   QueueView q, unsigned* __restrict__ cursor,
                                                   float4* __restrict__ hits, unsigned char* __restrict__ occ,
-                                                  unsigned long long* __restrict__ counters) {
+                                                  unsigned long long* __restrict__ counters,
+                                                  const int* __restrict__ remap, const unsigned* __restrict__ remapCount) {
+    // remap != nullptr: the queue is the list remap[0 .. *remapCount) of queue slots (the rays k_trace_wide handed
+    // back, kernels_trace_wide.hip); most launches find it empty
+    if (remap && *remapCount == 0u) return;
     __shared__ float4 top[2 * kTopNodes];
     __shared__ unsigned prefix[kShards + 1];
     const int lane = threadIdx.x & 63;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
         }
     }
     __syncthreads();
-    const unsigned total = q.counts ? prefix[kShards] : q.space;
+    const unsigned total = remap ? *remapCount : (q.counts ? prefix[kShards] : q.space);
     // explicit address spaces: with two generic pointers the compiler merges the two arms of "LDS or global" into one
     // flat load through a selected pointer, which sends the LDS lanes through the vector-memory path as well
     const __attribute__((address_space(3))) float4v* topLds = (const __attribute__((address_space(3))) float4v*)top;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                     chunkLeft = (total - base) < 64u ? (total - base) : 64u;
                     // shard of the chunk's first ray: the number of shards that end at or before it (one vote
                     // instead of a binary search per lane; lanes step on from here, usually zero times)
-                    if (q.counts) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= base));
+                    if (q.counts && !remap) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= base));
                 }
             }
             if (chunkLeft != 0) {
@@ -173,7 +177,9 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                 if (!hasRay && rank < take) {
                     const unsigned j = chunkBase + rank;  // dense ray index
                     unsigned slot = j;
-                    if (q.counts) {  // dense index -> shard: j < total = prefix[kShards] ends the loop
+                    if (remap) {
+                        slot = (unsigned)remap[j];
+                    } else if (q.counts) {  // dense index -> shard: j < total = prefix[kShards] ends the loop
                         unsigned sh = chunkShard;
                         while (j >= prefix[sh + 1]) ++sh;
                         slot = sh * q.regionSize + (j - prefix[sh]);
@@ -387,24 +393,26 @@ static inline unsigned trace_grid(size_t nMax) {
     return (unsigned)g;
 }
 void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
-                          unsigned* cursor, float4* hits, unsigned long long* counters) {
+                          unsigned* cursor, float4* hits, unsigned long long* counters, const int* remap,
+                          const unsigned* remapCount) {
     const unsigned g = trace_grid(q.space);
     if (counters)
         hipLaunchKernelGGL((k_trace<false, true>), dim3(g), dim3(kTraceBlock), 0, st, s, rays, index, nullptr, q, cursor, hits,
-                           nullptr, counters);
+                           nullptr, counters, remap, remapCount);
     else
         hipLaunchKernelGGL((k_trace<false, false>), dim3(g), dim3(kTraceBlock), 0, st, s, rays, index, nullptr, q, cursor, hits,
-                           nullptr, counters);
+                           nullptr, counters, remap, remapCount);
 }
 void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
-                           unsigned* cursor, unsigned char* occ, unsigned long long* counters) {
+                           unsigned* cursor, unsigned char* occ, unsigned long long* counters, const int* remap,
+                           const unsigned* remapCount) {
     const unsigned g = trace_grid(q.space);
     if (counters)
         hipLaunchKernelGGL((k_trace<true, true>), dim3(g), dim3(kTraceBlock), 0, st, s, rays, nullptr, target, q, cursor,
-                           nullptr, occ, counters);
+                           nullptr, occ, counters, remap, remapCount);
     else
         hipLaunchKernelGGL((k_trace<true, false>), dim3(g), dim3(kTraceBlock), 0, st, s, rays, nullptr, target, q, cursor,
-                           nullptr, occ, counters);
+                           nullptr, occ, counters, remap, remapCount);
 }
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays) {
     hipLaunchKernelGGL(k_eye_rays, dim3(grid_for(count)), dim3(kBlock), 0, st, cam, first, (unsigned)count, rays);

@@ -1,0 +1,337 @@
+// kernels_trace_wide.hip -- the order-free traversal over the 4-wide tree.
+//
+// Why the reference's results do not depend on HOW the leaves are found.  The reference walks its binary tree in a
+// fixed order and tests a leaf's triangles iff the leaf's box AND the boxes of all its ancestors pass
+// AABB::intersect (cs488.h:571-608, :1661-1683).  For a ray with finite, nonzero direction components and finite
+// operands every slab quotient RN(RN(plane - o) / d) is a monotone function of the plane, so for nested boxes
+// (child inside parent, which holds exactly for this BVH: a node's box is the min/max of its triangles, so the
+// parent's is the union of its children's -- build_wide() verifies it edge by edge) the entry distance of the
+// parent is <= the child's and its exit distance >= the child's: a leaf whose own box passes the predicate has
+// all its ancestors passing too.  Hence
+//     the triangles the reference tests  ==  the triangles of the leaves whose OWN box passes the exact predicate,
+// and its answer is the smallest accepted t among them, the first one in depth-first (= leafTris) order on a tie
+// (strict '<' in visit order, cs488.h:1674).  Any traversal may be used to find those leaves, in any order, with
+// any CONSERVATIVE test on the way (one that never rejects a box the exact predicate accepts), provided that
+//   * each candidate leaf is admitted by the exact predicate on its exact box (slab_hit_fast), and
+//   * ties in t are broken towards the smaller leafTris index.
+// isHit (cs488.h:1684-1705) returns "some accepted triangle exists", which is order-free by itself.
+//
+// This kernel does that for the rays that qualify (fast_div_ok, in a scene whose planes are tame and whose tree
+// build_wide() accepted): a 4-wide tree (one node = a binary node's grandchildren), all four boxes of a node
+// tested in straight-line code with a cheap conservative test (a * RN(1/d) instead of the exact division, widened
+// by 2^-20), a per-lane stack of one packed entry per level, leaves parked and opened later with the exact test.
+// One visit replaces four steps of the threaded walk (the walk spends as many issue slots on its exec-mask
+// juggling per box as on arithmetic: DESIGN.md).  Rays that do not qualify are appended to a list; the host runs
+// the literal walk (k_trace in kernels_trace.hip) over that list afterwards.
+#include "kernels.hpp"
+#include "shading.hpp"
+
+namespace ptd {
+
+#ifndef PT_TUNE_WIDE_BLOCK
+#define PT_TUNE_WIDE_BLOCK 512
+#endif
+#ifndef PT_TUNE_WIDE_WAVES
+#define PT_TUNE_WIDE_WAVES 4
+#endif
+#ifndef PT_TUNE_WIDE_BURST
+#define PT_TUNE_WIDE_BURST 2
+#endif
+#ifndef PT_TUNE_WIDE_REFILL
+#define PT_TUNE_WIDE_REFILL 16
+#endif
+#ifndef PT_TUNE_WIDE_LEAF
+#define PT_TUNE_WIDE_LEAF 40
+#endif
+#ifndef PT_TUNE_WIDE_KEEP
+#define PT_TUNE_WIDE_KEEP 16
+#endif
+#ifndef PT_TUNE_WIDE_STUCK
+#define PT_TUNE_WIDE_STUCK 8
+#endif
+constexpr int kWideBlock = PT_TUNE_WIDE_BLOCK;
+constexpr int kWideGroups = 4;  // leaf groups a lane may hold (one group = the leaf slots of one wide node)
+
+// The conservative slot test.  With y = RN(1/d): q~ = RN(a*y) and the exact q = RN(a/d) satisfy |q~ - q| <=
+// 2^-22 |q| (three roundings of 2^-24 each), q~ and q have the same sign and vanish together.  L(x) = x - 2^-21|x|
+// and U(x) = x + 2^-21|x| are increasing, L(q~) <= q <= U(q~), and min/max commute with increasing maps, so
+// t1 >= L(t1~), t2 <= U(t2~); the exact predicate max(t1, 0) <= t2 therefore implies max(L(t1~), 0) <= U(t2~).
+// The code widens by 2^-20, which also covers the rounding of its own two multiplications.
+__device__ __forceinline__ int wide_hit_mask(const float4v lox, const float4v hix, const float4v loy, const float4v hiy,
+                                             const float4v loz, const float4v hiz, const float ox, const float oy,
+                                             const float oz, const float yx, const float yy, const float yz) {
+    const float4v ax = (lox - ox) * yx, bx = (hix - ox) * yx;
+    const float4v ay = (loy - oy) * yy, by = (hiy - oy) * yy;
+    const float4v az = (loz - oz) * yz, bz = (hiz - oz) * yz;
+    const float4v t1 = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(ax, bx),
+                                                                           __builtin_elementwise_min(ay, by)),
+                                                 __builtin_elementwise_min(az, bz));
+    const float4v t2 = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(ax, bx),
+                                                                           __builtin_elementwise_max(ay, by)),
+                                                 __builtin_elementwise_max(az, bz));
+    const float4v u = __builtin_elementwise_max(t1 * 0x1.ffffep-1f, (float4v)(0.0f));  // 1 - 2^-20
+    const float4v v = t2 * 0x1.00001p0f;                                               // 1 + 2^-20
+    return (!(u.x > v.x) ? 1 : 0) | (!(u.y > v.y) ? 2 : 0) | (!(u.z > v.z) ? 4 : 0) | (!(u.w > v.w) ? 8 : 0);
+}
+
+// entry of the per-lane stacks: base << 8 | kindMask << 4 | pendingMask (pending != 0, so an entry is never 0);
+// slot k of the group is item  base + popcount(kindMask & ((1 << k) - 1))
+__device__ __forceinline__ unsigned pack_group(int base, int kindMask, int pending) {
+    return ((unsigned)base << 8) | ((unsigned)kindMask << 4) | (unsigned)pending;
+}
+__device__ __forceinline__ int group_take(unsigned& e) {  // removes the lowest pending slot, returns its item
+    const unsigned pend = e & 15u;
+    const unsigned bit = pend & (0u - pend);
+    e &= ~bit;
+    return (int)(e >> 8) + __popc((e >> 4) & 15u & (bit - 1u));
+}
+
+#define PT_WIDE_ATTR __attribute__((amdgpu_waves_per_eu(PT_TUNE_WIDE_WAVES, PT_TUNE_WIDE_WAVES)))
+
+template <bool ANYHIT, bool COUNT>
+__global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
+    DevScene s, const float4* __restrict__ rays, const int* __restrict__ index, const int* __restrict__ target,
+    QueueView q, unsigned* __restrict__ cursor, float4* __restrict__ hits, unsigned char* __restrict__ occ,
+    unsigned long long* __restrict__ counters, unsigned* __restrict__ slowCount, int* __restrict__ slowList) {
+    __shared__ float4 top[kWideNodeF4 * kWideTopNodes];
+    __shared__ unsigned stackLds[kWideMaxDepth * kWideBlock];  // entry d of lane t at [d * kWideBlock + t]
+    __shared__ unsigned prefix[kShards + 1];
+    const int lane = threadIdx.x & 63;
+    const int nTop = s.nWideTop;
+    for (int i = threadIdx.x; i < kWideNodeF4 * nTop; i += kWideBlock) top[i] = s.wnodes[i];
+    if (q.counts) {
+        if (threadIdx.x < 64) {
+            unsigned v = q.counts[(size_t)lane * kCntStride];
+            for (int off = 1; off < 64; off <<= 1) {  // inclusive scan over the 64 shard counts
+                const unsigned up = __shfl_up(v, off);
+                if (lane >= off) v += up;
+            }
+            prefix[lane + 1] = v;
+            if (lane == 0) prefix[0] = 0;
+        }
+    }
+    __syncthreads();
+    const unsigned total = q.counts ? prefix[kShards] : q.space;
+    const __attribute__((address_space(3))) float4v* topLds = (const __attribute__((address_space(3))) float4v*)top;
+    const __attribute__((address_space(1))) float4v* nodesGlobal = (const __attribute__((address_space(1))) float4v*)s.wnodes;
+
+    // lane state
+    bool hasRay = false;
+    int w = -1;             // next wide node to visit (-1: the walk is over)
+    unsigned tos = 0;       // top of the stack of interior groups (0: none); older entries in stack[0..sp)
+    __attribute__((address_space(3))) unsigned* stack = (__attribute__((address_space(3))) unsigned*)stackLds + threadIdx.x;
+    int sp = 0;  // in units of kWideBlock entries
+    // leaf groups still to be opened (LIFO, g0 on top; order is free) and the open leaf's triangle cursor
+    int groups = 0;
+    unsigned g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+    int cur = -1;
+    unsigned raySlot = 0, queueSlot = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
+    float tMin = 0.0f, tMax = 0.0f;
+    int bestTri = -1, bestSeq = 0x7fffffff;
+    float bestT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;
+    unsigned nv = 0, nt = 0;
+    unsigned chunkBase = 0, chunkLeft = 0, chunkShard = 0;
+    bool exhausted = (total == 0);
+
+#define PT_FINISH()                                                                        \
+    do {                                                                                   \
+        if (ANYHIT) {                                                                      \
+            if (bestTri >= 0) occ[target ? (unsigned)target[queueSlot] : queueSlot] = 1;   \
+        } else {                                                                           \
+            hits[raySlot] = make_float4(i2f(bestTri), bestT, bestB, bestG);                \
+        }                                                                                  \
+        hasRay = false;                                                                    \
+        w = -1;                                                                            \
+        tos = 0;                                                                           \
+        sp = 0;                                                                            \
+        groups = 0;                                                                        \
+        cur = -1;                                                                          \
+    } while (0)
+
+    while (true) {
+        const unsigned long long mEmpty = __ballot(!hasRay);
+        const int nEmpty = __popcll(mEmpty);
+        if (nEmpty == 64 && exhausted) break;
+        if (!exhausted && nEmpty >= PT_TUNE_WIDE_REFILL) {
+            // ---- refill: empty lanes take the next rays of the queue ----
+            if (chunkLeft == 0) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(cursor, 64u);
+                base = __shfl(base, 0);
+                if (base >= total) {
+                    exhausted = true;
+                } else {
+                    chunkBase = base;
+                    chunkLeft = (total - base) < 64u ? (total - base) : 64u;
+                    if (q.counts) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= base));
+                }
+            }
+            if (chunkLeft != 0) {
+                const unsigned rank = (unsigned)__popcll(mEmpty & ((1ull << lane) - 1ull));
+                const unsigned take = chunkLeft < (unsigned)nEmpty ? chunkLeft : (unsigned)nEmpty;
+                bool slow = false;
+                unsigned slot = 0;
+                if (!hasRay && rank < take) {
+                    const unsigned j = chunkBase + rank;  // dense ray index
+                    slot = j;
+                    if (q.counts) {  // dense index -> shard: j < total = prefix[kShards] ends the loop
+                        unsigned sh = chunkShard;
+                        while (j >= prefix[sh + 1]) ++sh;
+                        slot = sh * q.regionSize + (j - prefix[sh]);
+                    }
+                    queueSlot = slot;
+                    raySlot = index ? (unsigned)index[slot] : slot;
+                    const size_t rs = ANYHIT ? (size_t)slot : (size_t)raySlot;  // shadow rays live in queue order
+                    const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
+                    ox = r0.x; oy = r0.y; oz = r0.z; tMin = r0.w;
+                    dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
+                    if (fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz})) {
+                        yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
+                        bestTri = -1; bestSeq = 0x7fffffff; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
+                        w = 0;
+                        hasRay = true;
+                    } else {
+                        slow = true;  // this ray takes the literal walk in a later launch
+                    }
+                }
+                const unsigned long long mSlow = __ballot(slow);
+                if (mSlow != 0ull) {
+                    unsigned at = 0;
+                    if (lane == 0) at = atomicAdd(slowCount, (unsigned)__popcll(mSlow));
+                    at = __shfl(at, 0);
+                    if (slow) slowList[at + (unsigned)__popcll(mSlow & ((1ull << lane) - 1ull))] = (int)slot;
+                }
+                chunkBase += take;
+                chunkLeft -= take;
+            }
+            if (nEmpty == 64) continue;  // nothing else to do yet
+        }
+        // ---- visits: lanes with a node to visit and room for one more leaf group ----
+#pragma unroll
+        for (int b = 0; b < PT_TUNE_WIDE_BURST; b++) {
+            if (w >= 0 && groups < kWideGroups) {
+                float4v lox, hix, loy, hiy, loz, hiz, meta;
+                if (w < nTop) {  // top of the tree: from LDS
+                    const int a = kWideNodeF4 * w;
+                    lox = topLds[a]; hix = topLds[a + 1]; loy = topLds[a + 2]; hiy = topLds[a + 3];
+                    loz = topLds[a + 4]; hiz = topLds[a + 5]; meta = topLds[a + 6];
+                } else {
+                    const size_t a = (size_t)kWideNodeF4 * (size_t)w;
+                    lox = nodesGlobal[a]; hix = nodesGlobal[a + 1]; loy = nodesGlobal[a + 2]; hiy = nodesGlobal[a + 3];
+                    loz = nodesGlobal[a + 4]; hiz = nodesGlobal[a + 5]; meta = nodesGlobal[a + 6];
+                }
+                const int masks = f2i(meta.z);
+                const int imask = masks & 15, lmask = (masks >> 4) & 15;
+                if (COUNT) nv += (unsigned)__popc((unsigned)(imask | lmask));
+                const int hm = wide_hit_mask(lox, hix, loy, hiy, loz, hiz, ox, oy, oz, yx, yy, yz);
+                const int lh = hm & lmask, ih = hm & imask;
+                if (lh != 0) {  // park the candidate leaves of this node as one group
+                    g3 = g2; g2 = g1; g1 = g0;
+                    g0 = pack_group(f2i(meta.y), lmask, lh);
+                    ++groups;
+                }
+                if (ih != 0) {  // go down into the first hit child, keep the others as one stack entry
+                    unsigned e = pack_group(f2i(meta.x), imask, ih);
+                    w = group_take(e);
+                    if ((e & 15u) != 0u) {
+                        if (tos != 0u) { stack[sp] = tos; sp += kWideBlock; }
+                        tos = e;
+                    }
+                } else if (tos != 0u) {  // nothing below: on to the pending child nearest on the stack
+                    w = group_take(tos);
+                    if ((tos & 15u) == 0u) {
+                        if (sp > 0) { sp -= kWideBlock; tos = stack[sp]; } else tos = 0u;
+                    }
+                } else {
+                    w = -1;
+                    if (groups == 0 && cur < 0) PT_FINISH();
+                }
+            }
+        }
+        // ---- leaves: open parked leaves with the exact box test, test their triangles ----
+        const unsigned long long mCanVisit = __ballot(w >= 0 && groups < kWideGroups);
+        unsigned long long mPend = __ballot(cur >= 0 || groups > 0);
+        const unsigned long long mStuck = mPend & ~mCanVisit;
+        if (mPend != 0ull && (__popcll(mPend) >= PT_TUNE_WIDE_LEAF || __popcll(mStuck) >= PT_TUNE_WIDE_STUCK || mCanVisit == 0ull)) {
+            do {
+                if (cur < 0 && groups > 0) {  // open the next leaf of the top group
+                    const int leaf = group_take(g0);
+                    const float4v b0 = ((const __attribute__((address_space(1))) float4v*)s.leafBox)[2 * (size_t)leaf];
+                    const float4v b1 = ((const __attribute__((address_space(1))) float4v*)s.leafBox)[2 * (size_t)leaf + 1];
+                    if (COUNT) nv++;
+                    if (slab_hit_fast(b0, b1, ox, oy, oz, dx, dy, dz, yx, yy, yz)) cur = f2i(b1.z);  // the reference's predicate
+                    if ((g0 & 15u) == 0u) {
+                        g0 = g1; g1 = g2; g2 = g3;
+                        --groups;
+                    }
+                }
+                if (cur >= 0) {  // one triangle of the open leaf (cs488.h:1671-1675 / 1693-1697)
+                    const float4 q0 = s.leafTris[3 * (size_t)cur];
+                    const float4 q1 = s.leafTris[3 * (size_t)cur + 1];
+                    const float4 q2 = s.leafTris[3 * (size_t)cur + 2];
+                    if (COUNT) nt++;
+                    float t, be, ga;
+                    const bool acc = tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z},
+                                              vec3{ox, oy, oz}, vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
+                    // the reference keeps the FIRST of equal t's in depth-first order: smaller leafTris index wins
+                    if (acc && (ANYHIT || t < bestT || (t == bestT && cur < bestSeq))) {
+                        bestTri = f2i(q0.w); bestSeq = cur; bestT = t; bestB = be; bestG = ga;
+                    }
+                    if (ANYHIT && acc) {
+                        PT_FINISH();  // isHit: any accepted triangle decides
+                    } else if (f2i(q1.w)) {
+                        cur = -1;  // last triangle of this leaf
+                    } else {
+                        ++cur;
+                    }
+                }
+                if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();
+                mPend = __ballot(cur >= 0 || groups > 0);
+            } while (__popcll(mPend) >= PT_TUNE_WIDE_KEEP);
+        }
+    }
+#undef PT_FINISH
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) {  // wave-level reduction, one atomic pair per wavefront
+            nv += __shfl_down(nv, off);
+            nt += __shfl_down(nt, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], (unsigned long long)nv);
+            atomicAdd(&counters[1], (unsigned long long)nt);
+        }
+    }
+}
+
+static inline unsigned wide_grid(size_t nMax) {
+    size_t g = (nMax + kWideBlock - 1) / kWideBlock;
+    if (g < 1) g = 1;
+    const size_t cap = (size_t)256 * 2;  // two blocks per CU: their LDS (the top of the wide tree) fills it
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+void launch_trace_wide_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
+                               unsigned* cursor, float4* hits, unsigned long long* counters, unsigned* slowCount,
+                               int* slowList) {
+    const unsigned g = wide_grid(q.space);
+    if (counters)
+        hipLaunchKernelGGL((k_trace_wide<false, true>), dim3(g), dim3(kWideBlock), 0, st, s, rays, index, nullptr, q, cursor,
+                           hits, nullptr, counters, slowCount, slowList);
+    else
+        hipLaunchKernelGGL((k_trace_wide<false, false>), dim3(g), dim3(kWideBlock), 0, st, s, rays, index, nullptr, q, cursor,
+                           hits, nullptr, counters, slowCount, slowList);
+}
+void launch_trace_wide_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
+                                unsigned* cursor, unsigned char* occ, unsigned long long* counters, unsigned* slowCount,
+                                int* slowList) {
+    const unsigned g = wide_grid(q.space);
+    if (counters)
+        hipLaunchKernelGGL((k_trace_wide<true, true>), dim3(g), dim3(kWideBlock), 0, st, s, rays, nullptr, target, q, cursor,
+                           nullptr, occ, counters, slowCount, slowList);
+    else
+        hipLaunchKernelGGL((k_trace_wide<true, false>), dim3(g), dim3(kWideBlock), 0, st, s, rays, nullptr, target, q, cursor,
+                           nullptr, occ, counters, slowCount, slowList);
+}
+
+}  // namespace ptd
