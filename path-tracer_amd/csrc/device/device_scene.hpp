@@ -75,11 +75,15 @@ constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's pe
 #ifndef PT_TUNE_WIDE_BLOCK
 #define PT_TUNE_WIDE_BLOCK 512
 #endif
-// LDS of one k_trace_wide block (two blocks per CU, 80 KB each): the per-lane stacks (kWideMaxDepth words per lane),
-// the shard prefix sums, and the first kWideTopNodes wide nodes (112 B each)
-#ifndef PT_TUNE_WIDE_TOP
-#define PT_TUNE_WIDE_TOP ((81920 - 320 - 4 * kWideMaxDepth * PT_TUNE_WIDE_BLOCK) / 112)
+#ifndef PT_TUNE_WIDE_PER_CU
+#define PT_TUNE_WIDE_PER_CU 2
 #endif
+// LDS of one k_trace_wide block (PT_TUNE_WIDE_PER_CU blocks share a CU's 160 KB): the per-lane stacks (kWideMaxDepth
+// words per lane), the shard prefix sums, and the first kWideTopNodes wide nodes (112 B each)
+#ifndef PT_TUNE_WIDE_TOP
+#define PT_TUNE_WIDE_TOP ((163840 / PT_TUNE_WIDE_PER_CU - 320 - 4 * kWideMaxDepth * PT_TUNE_WIDE_BLOCK) / 112)
+#endif
+constexpr int kWideBlocksPerCU = PT_TUNE_WIDE_PER_CU;
 constexpr int kWideTopNodes = PT_TUNE_WIDE_TOP;
 constexpr int kTraceGrid = PT_TUNE_GRID;  // persistent grid of k_trace: blocks per CU x 256 CUs
 constexpr int kTopNodes = PT_TUNE_TOP;   // nodes k_trace keeps in LDS (32 B each; with the shard prefix sums just under 64 KB)

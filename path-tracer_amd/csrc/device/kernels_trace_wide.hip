@@ -35,7 +35,7 @@ namespace ptd {
 #define PT_TUNE_WIDE_WAVES 4
 #endif
 #ifndef PT_TUNE_WIDE_BURST
-#define PT_TUNE_WIDE_BURST 2
+#define PT_TUNE_WIDE_BURST 4
 #endif
 #ifndef PT_TUNE_WIDE_REFILL
 #define PT_TUNE_WIDE_REFILL 16
@@ -57,18 +57,17 @@ constexpr int kWideGroups = 4;  // leaf groups a lane may hold (one group = the 
 // and U(x) = x + 2^-21|x| are increasing, L(q~) <= q <= U(q~), and min/max commute with increasing maps, so
 // t1 >= L(t1~), t2 <= U(t2~); the exact predicate max(t1, 0) <= t2 therefore implies max(L(t1~), 0) <= U(t2~).
 // The code widens by 2^-20, which also covers the rounding of its own two multiplications.
-__device__ __forceinline__ int wide_hit_mask(const float4v lox, const float4v hix, const float4v loy, const float4v hiy,
-                                             const float4v loz, const float4v hiz, const float ox, const float oy,
+// nearx .. farz: the node's plane rows already picked by the ray's direction signs (min row where d > 0, max row
+// where d < 0 for "near", the other one for "far"): the products are monotone in the plane, so these ARE
+// min(a, b) / max(a, b) of the two candidates, without computing both.
+__device__ __forceinline__ int wide_hit_mask(const float4v nearx, const float4v farx, const float4v neary, const float4v fary,
+                                             const float4v nearz, const float4v farz, const float ox, const float oy,
                                              const float oz, const float yx, const float yy, const float yz) {
-    const float4v ax = (lox - ox) * yx, bx = (hix - ox) * yx;
-    const float4v ay = (loy - oy) * yy, by = (hiy - oy) * yy;
-    const float4v az = (loz - oz) * yz, bz = (hiz - oz) * yz;
-    const float4v t1 = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(ax, bx),
-                                                                           __builtin_elementwise_min(ay, by)),
-                                                 __builtin_elementwise_min(az, bz));
-    const float4v t2 = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(ax, bx),
-                                                                           __builtin_elementwise_max(ay, by)),
-                                                 __builtin_elementwise_max(az, bz));
+    const float4v nx = (nearx - ox) * yx, fx = (farx - ox) * yx;
+    const float4v ny = (neary - oy) * yy, fy = (fary - oy) * yy;
+    const float4v nz = (nearz - oz) * yz, fz = (farz - oz) * yz;
+    const float4v t1 = __builtin_elementwise_max(__builtin_elementwise_max(nx, ny), nz);
+    const float4v t2 = __builtin_elementwise_min(__builtin_elementwise_min(fx, fy), fz);
     const float4v u = __builtin_elementwise_max(t1 * 0x1.ffffep-1f, (float4v)(0.0f));  // 1 - 2^-20
     const float4v v = t2 * 0x1.00001p0f;                                               // 1 + 2^-20
     return (!(u.x > v.x) ? 1 : 0) | (!(u.y > v.y) ? 2 : 0) | (!(u.z > v.z) ? 4 : 0) | (!(u.w > v.w) ? 8 : 0);
@@ -127,6 +126,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     int cur = -1;
     unsigned raySlot = 0, queueSlot = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
+    int sx = 0, sy = 0, sz = 0;  // 1 where the direction component is negative
     float tMin = 0.0f, tMax = 0.0f;
     int bestTri = -1, bestSeq = 0x7fffffff;
     float bestT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
                     if (fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz})) {
                         yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
+                        sx = dx < 0.0f ? 1 : 0; sy = dy < 0.0f ? 1 : 0; sz = dz < 0.0f ? 1 : 0;
                         bestTri = -1; bestSeq = 0x7fffffff; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
                         w = 0;
                         hasRay = true;
@@ -211,20 +212,21 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
 #pragma unroll
         for (int b = 0; b < PT_TUNE_WIDE_BURST; b++) {
             if (w >= 0 && groups < kWideGroups) {
-                float4v lox, hix, loy, hiy, loz, hiz, meta;
+                float4v nearx, farx, neary, fary, nearz, farz, meta;  // rows picked by the direction signs (sx, sy, sz)
                 if (w < nTop) {  // top of the tree: from LDS
                     const int a = kWideNodeF4 * w;
-                    lox = topLds[a]; hix = topLds[a + 1]; loy = topLds[a + 2]; hiy = topLds[a + 3];
-                    loz = topLds[a + 4]; hiz = topLds[a + 5]; meta = topLds[a + 6];
+                    nearx = topLds[a + sx]; farx = topLds[a + (sx ^ 1)]; neary = topLds[a + 2 + sy]; fary = topLds[a + 2 + (sy ^ 1)];
+                    nearz = topLds[a + 4 + sz]; farz = topLds[a + 4 + (sz ^ 1)]; meta = topLds[a + 6];
                 } else {
                     const size_t a = (size_t)kWideNodeF4 * (size_t)w;
-                    lox = nodesGlobal[a]; hix = nodesGlobal[a + 1]; loy = nodesGlobal[a + 2]; hiy = nodesGlobal[a + 3];
-                    loz = nodesGlobal[a + 4]; hiz = nodesGlobal[a + 5]; meta = nodesGlobal[a + 6];
+                    nearx = nodesGlobal[a + sx]; farx = nodesGlobal[a + (sx ^ 1)]; neary = nodesGlobal[a + 2 + sy];
+                    fary = nodesGlobal[a + 2 + (sy ^ 1)]; nearz = nodesGlobal[a + 4 + sz]; farz = nodesGlobal[a + 4 + (sz ^ 1)];
+                    meta = nodesGlobal[a + 6];
                 }
                 const int masks = f2i(meta.z);
                 const int imask = masks & 15, lmask = (masks >> 4) & 15;
                 if (COUNT) nv += (unsigned)__popc((unsigned)(imask | lmask));
-                const int hm = wide_hit_mask(lox, hix, loy, hiy, loz, hiz, ox, oy, oz, yx, yy, yz);
+                const int hm = wide_hit_mask(nearx, farx, neary, fary, nearz, farz, ox, oy, oz, yx, yy, yz);
                 const int lh = hm & lmask, ih = hm & imask;
                 if (lh != 0) {  // park the candidate leaves of this node as one group
                     g3 = g2; g2 = g1; g1 = g0;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
 static inline unsigned wide_grid(size_t nMax) {
     size_t g = (nMax + kWideBlock - 1) / kWideBlock;
     if (g < 1) g = 1;
-    const size_t cap = (size_t)256 * 2;  // two blocks per CU: their LDS (the top of the wide tree) fills it
+    const size_t cap = (size_t)256 * kWideBlocksPerCU;  // as many blocks as fit the CUs' LDS at once
     if (g > cap) g = cap;
     return (unsigned)g;
 }

@@ -18,7 +18,8 @@ for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}", "*", "*", "*co
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].split("::")[-1]
         if "k_trace" in name:
-            name = ("k_trace_occluded" if "k_trace<true" in name else "k_trace_closest") + ("_count" if ", true>" in name else "")
+            base = "k_trace_wide" if "k_trace_wide" in name else "k_trace"
+            name = base + ("_occluded" if "<true" in name else "_closest") + ("_count" if ", true>" in name else "")
         agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[name][r["Counter_Name"]] += 1
 out = {}
@@ -54,7 +55,7 @@ for k, d in out.items():
             print(f"    {c}: {d[c]:.4g}")
 if "--traffic" in sys.argv:
     t = {}
-    for k in ("k_trace_closest", "k_trace_occluded"):
+    for k in ("k_trace_closest", "k_trace_occluded", "k_trace_wide_closest", "k_trace_wide_occluded"):
         if k in out and "hbm_read_bytes_per_launch" in out[k]:
             t[k] = {"hbm_bytes_per_launch": out[k]["hbm_read_bytes_per_launch"] + out[k].get("hbm_write_bytes_per_launch", 0.0),
                     "source": f"profiles/{rnd}/pmc_{tag}.json: 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes of "

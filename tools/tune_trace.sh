@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds variants of libmipt.so that differ in k_trace's scheduling constants (-DPT_TUNE_..., kernels_trace.hip) into
+# Builds variants of libmipt.so that differ in the traversal kernels' scheduling constants (-DPT_TUNE_..., kernels_trace*.hip) into
 # build_variants/ (CPU side, before the GPU call):    bash tools/tune_trace.sh build name1 "-DPT_TUNE_REFILL=8" name2 "..."
 # and benches ONE built variant on the GPU box:    bash tools/tune_trace.sh bench <name>   (one variant per gpurun call)
 set -e
@@ -14,10 +14,11 @@ if [ "$1" = build ]; then
   while [ $# -ge 2 ]; do
     name=$1; defs=$2; shift 2
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src/device/kernels_trace.hip -o $out/kt_$name.o
-    /opt/rocm/bin/hipcc $FLAGS $defs -c $src/api/api_device.hip -o $out/api_$name.o   # kTopNodes is used on the host side too
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libmipt_$name.so $out/kt_$name.o $src/device/kernels_integrate.o \
+    /opt/rocm/bin/hipcc $FLAGS $defs -c $src/device/kernels_trace_wide.hip -o $out/kw_$name.o
+    /opt/rocm/bin/hipcc $FLAGS $defs -c $src/api/api_device.hip -o $out/api_$name.o   # kTopNodes / kWideTopNodes are used on the host side too
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libmipt_$name.so $out/kt_$name.o $out/kw_$name.o $src/device/kernels_integrate.o \
         $out/api_$name.o $src/api/api_host.o $src/host/obj_loader.o $src/host/bvh_build.o $src/host/image_io.o -lz
-    rm -f $out/kt_$name.o $out/api_$name.o
+    rm -f $out/kt_$name.o $out/kw_$name.o $out/api_$name.o
     echo "built $name ($defs)"
   done
 elif [ "$1" = bench ]; then
