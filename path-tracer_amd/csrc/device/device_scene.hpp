@@ -17,8 +17,9 @@
 //               {bits(childBase), bits(leafBase), bits(interiorMask | leafMask << 4), 0}
 //             interior child of slot k = childBase + popcount(interiorMask & ((1 << k) - 1)),
 //             leaf of slot k = leafBase + popcount(leafMask & ((1 << k) - 1))
-//   leafBox   2 x float4 per leaf (wide leaf numbering): {min.x, max.x, min.y, max.y} {min.z, max.z, bits(first
-//             leaf triangle), 0} -- the leaf's exact box, tested with the reference's exact predicate
+//   leafBox   5 x float4 per leaf (wide leaf numbering): {min.x, max.x, min.y, max.y} {min.z, max.z, bits(first
+//             leaf triangle), 0} -- the leaf's exact box, tested with the reference's exact predicate -- followed by
+//             a copy of the leaf's first leafTris record, so that opening a leaf is ONE round trip to memory
 //   leafTris  3 x float4 per triangle reference (48 B), in leaf (triList) order:
 //               {p0.xyz, bits(original triangle id)}
 //               {p0-p1,  bits(1 if last triangle of its leaf)}
@@ -71,12 +72,13 @@ constexpr int kTraceBlock = PT_TUNE_BLOCK;  // k_trace: 16 wavefronts per block,
 #define PT_TUNE_GRID 512
 #endif
 constexpr int kWideNodeF4 = 7;      // float4 per wide node
+constexpr int kLeafRecF4 = 5;       // float4 per leafBox record
 constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's per-lane stack can hold (binary depth 32)
 #ifndef PT_TUNE_WIDE_BLOCK
-#define PT_TUNE_WIDE_BLOCK 512
+#define PT_TUNE_WIDE_BLOCK 1024
 #endif
 #ifndef PT_TUNE_WIDE_PER_CU
-#define PT_TUNE_WIDE_PER_CU 2
+#define PT_TUNE_WIDE_PER_CU 1
 #endif
 // LDS of one k_trace_wide block (PT_TUNE_WIDE_PER_CU blocks share a CU's 160 KB): the per-lane stacks (kWideMaxDepth
 // words per lane), the shard prefix sums, and the first kWideTopNodes wide nodes (112 B each)

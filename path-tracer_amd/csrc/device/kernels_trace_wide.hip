@@ -29,7 +29,7 @@
 namespace ptd {
 
 #ifndef PT_TUNE_WIDE_BLOCK
-#define PT_TUNE_WIDE_BLOCK 512
+#define PT_TUNE_WIDE_BLOCK 1024
 #endif
 #ifndef PT_TUNE_WIDE_WAVES
 #define PT_TUNE_WIDE_WAVES 4
@@ -52,14 +52,17 @@ namespace ptd {
 constexpr int kWideBlock = PT_TUNE_WIDE_BLOCK;
 constexpr int kWideGroups = 4;  // leaf groups a lane may hold (one group = the leaf slots of one wide node)
 
-// The conservative slot test.  With y = RN(1/d): q~ = RN(a*y) and the exact q = RN(a/d) satisfy |q~ - q| <=
-// 2^-22 |q| (three roundings of 2^-24 each), q~ and q have the same sign and vanish together.  L(x) = x - 2^-21|x|
-// and U(x) = x + 2^-21|x| are increasing, L(q~) <= q <= U(q~), and min/max commute with increasing maps, so
-// t1 >= L(t1~), t2 <= U(t2~); the exact predicate max(t1, 0) <= t2 therefore implies max(L(t1~), 0) <= U(t2~).
-// The code widens by 2^-20, which also covers the rounding of its own two multiplications.
+// The conservative slot test.  With y = RN(1/d): q~ = RN(RN(p - o) * y) and the exact q = RN(RN(p - o) / d)
+// satisfy |q~ - q| <= 2^-22 |q| (three roundings of 2^-24 each), q~ and q have the same sign and vanish together.
+// L(x) = x - 2^-21|x| and U(x) = x + 2^-21|x| are increasing, L(q~) <= q <= U(q~), and min/max commute with
+// increasing maps, so t1 >= L(t1~), t2 <= U(t2~); the exact predicate max(t1, 0) <= t2 therefore implies
+// max(L(t1~), 0) <= U(t2~).  The code widens by 2^-20, which also covers the rounding of its own two
+// multiplications (for t1~ < 0 the clamp makes the shape of L irrelevant, for t2~ < 0 both forms reject).
 // nearx .. farz: the node's plane rows already picked by the ray's direction signs (min row where d > 0, max row
 // where d < 0 for "near", the other one for "far"): the products are monotone in the plane, so these ARE
-// min(a, b) / max(a, b) of the two candidates, without computing both.
+// min / max of the two candidates, without computing both.
+// (Folding subtraction and multiplication into one fma per plane, fma(p, y, -o*y) with an absolute slack for the
+// cancellation, was measured 20 % slower although it halves the arithmetic; not understood, not kept.)
 __device__ __forceinline__ int wide_hit_mask(const float4v nearx, const float4v farx, const float4v neary, const float4v fary,
                                              const float4v nearz, const float4v farz, const float ox, const float oy,
                                              const float oz, const float yx, const float yy, const float yz) {
@@ -257,35 +260,51 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         const unsigned long long mStuck = mPend & ~mCanVisit;
         if (mPend != 0ull && (__popcll(mPend) >= PT_TUNE_WIDE_LEAF || __popcll(mStuck) >= PT_TUNE_WIDE_STUCK || mCanVisit == 0ull)) {
             do {
-                if (cur < 0 && groups > 0) {  // open the next leaf of the top group
-                    const int leaf = group_take(g0);
-                    const float4v b0 = ((const __attribute__((address_space(1))) float4v*)s.leafBox)[2 * (size_t)leaf];
-                    const float4v b1 = ((const __attribute__((address_space(1))) float4v*)s.leafBox)[2 * (size_t)leaf + 1];
-                    if (COUNT) nv++;
-                    if (slab_hit_fast(b0, b1, ox, oy, oz, dx, dy, dz, yx, yy, yz)) cur = f2i(b1.z);  // the reference's predicate
-                    if ((g0 & 15u) == 0u) {
-                        g0 = g1; g1 = g2; g2 = g3;
-                        --groups;
-                    }
-                }
-                if (cur >= 0) {  // one triangle of the open leaf (cs488.h:1671-1675 / 1693-1697)
-                    const float4 q0 = s.leafTris[3 * (size_t)cur];
-                    const float4 q1 = s.leafTris[3 * (size_t)cur + 1];
-                    const float4 q2 = s.leafTris[3 * (size_t)cur + 2];
-                    if (COUNT) nt++;
-                    float t, be, ga;
-                    const bool acc = tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z},
-                                              vec3{ox, oy, oz}, vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
-                    // the reference keeps the FIRST of equal t's in depth-first order: smaller leafTris index wins
-                    if (acc && (ANYHIT || t < bestT || (t == bestT && cur < bestSeq))) {
-                        bestTri = f2i(q0.w); bestSeq = cur; bestT = t; bestB = be; bestG = ga;
-                    }
-                    if (ANYHIT && acc) {
-                        PT_FINISH();  // isHit: any accepted triangle decides
-                    } else if (f2i(q1.w)) {
-                        cur = -1;  // last triangle of this leaf
+                // One round trip per iteration: a lane either opens the next leaf of its top group (exact box +
+                // the leaf's first triangle, one 80-B record) or goes on with the next triangle of its open leaf.
+                const bool opening = cur < 0 && groups > 0;
+                const bool testing = cur >= 0 || opening;
+                if (testing) {
+                    const __attribute__((address_space(1))) float4v* triAt;
+                    float4v b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+                    if (opening) {
+                        const int leaf = group_take(g0);
+                        const __attribute__((address_space(1))) float4v* rec =
+                            (const __attribute__((address_space(1))) float4v*)s.leafBox + (size_t)kLeafRecF4 * (size_t)leaf;
+                        b0 = rec[0]; b1 = rec[1];
+                        triAt = rec + 2;
+                        if ((g0 & 15u) == 0u) {
+                            g0 = g1; g1 = g2; g2 = g3;
+                            --groups;
+                        }
                     } else {
-                        ++cur;
+                        triAt = (const __attribute__((address_space(1))) float4v*)s.leafTris + 3 * (size_t)cur;
+                    }
+                    const float4v q0 = triAt[0], q1 = triAt[1], q2 = triAt[2];
+                    bool valid = true;
+                    if (opening) {
+                        if (COUNT) nv++;
+                        valid = slab_hit_fast(b0, b1, ox, oy, oz, dx, dy, dz, yx, yy, yz);  // the reference's predicate
+                        cur = f2i(b1.z);
+                    }
+                    if (valid) {  // one triangle (cs488.h:1671-1675 / 1693-1697)
+                        if (COUNT) nt++;
+                        float t, be, ga;
+                        const bool acc = tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z},
+                                                  vec3{ox, oy, oz}, vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
+                        // the reference keeps the FIRST of equal t's in depth-first order: smaller leafTris index wins
+                        if (acc && (ANYHIT || t < bestT || (t == bestT && cur < bestSeq))) {
+                            bestTri = f2i(q0.w); bestSeq = cur; bestT = t; bestB = be; bestG = ga;
+                        }
+                        if (ANYHIT && acc) {
+                            PT_FINISH();  // isHit: any accepted triangle decides
+                        } else if (f2i(q1.w)) {
+                            cur = -1;  // last triangle of this leaf
+                        } else {
+                            ++cur;
+                        }
+                    } else {
+                        cur = -1;  // the leaf's own box is missed: the reference does not test its triangles
                     }
                 }
                 if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();
