@@ -439,6 +439,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
 
 void mipt_scene_destroy(mipt_scene* s) { delete s; }
 int mipt_scene_exact_reciprocal(const mipt_scene* s) { return (s && s->planesTame) ? 1 : 0; }
+int mipt_scene_wide_nodes(const mipt_scene* s) { return (s && s->wideOk) ? s->nWide : 0; }
 
 int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx** out) {
     if (!s || !out) return fail(MIPT_ERR_INVALID, "mipt_context_create: null argument");

@@ -61,8 +61,9 @@ constexpr int kWideGroups = 4;  // leaf groups a lane may hold (one group = the 
 // nearx .. farz: the node's plane rows already picked by the ray's direction signs (min row where d > 0, max row
 // where d < 0 for "near", the other one for "far"): the products are monotone in the plane, so these ARE
 // min / max of the two candidates, without computing both.
-// (Folding subtraction and multiplication into one fma per plane, fma(p, y, -o*y) with an absolute slack for the
-// cancellation, was measured 20 % slower although it halves the arithmetic; not understood, not kept.)
+// (Folding subtraction and multiplication into one fma per plane, fma(p, y, -o*y), needs an absolute slack of
+// 2^-24 |o*y| for the cancellation; for rays with one tiny direction component that slack is as large as the
+// scene, those rays visit thousands of nodes and the launch waits for them: measured 20 % slower, not kept.)
 __device__ __forceinline__ int wide_hit_mask(const float4v nearx, const float4v farx, const float4v neary, const float4v fary,
                                              const float4v nearz, const float4v farz, const float ox, const float oy,
                                              const float oz, const float yx, const float yy, const float yz) {

@@ -196,3 +196,36 @@ def test_rays_straddling_reciprocal_preconditions(B, ob, sf):
     assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[2]), bits(b[2]))
     occ = ctx.occluded(o, d, 1e-4, 2.5)
     assert np.array_equal(occ, orc.occluded(o, d, 1e-4, 2.5))
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "teapot-glass", "testObj"])
+def test_literal_walk_and_wide_traversal_agree(B, ob, sf, name, monkeypatch):
+    """MIPT_TRAVERSAL=walk forces the literal threaded walk (k_trace) for a context; both it and the default
+    order-free traversal over the 4-wide tree (k_trace_wide) must reproduce the oracle bit for bit, on primary
+    rays and on incoherent rays from random points (the wide kernel's stack and leaf groups in all states)"""
+    arrays = sf.load_scene_arrays(name)
+    scene = sf.product_scene_from_mesh_arrays(*arrays)
+    assert scene.wide_nodes > 0
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+    wide_ctx = B.Context(scene, device=0)
+    monkeypatch.setenv("MIPT_TRAVERSAL", "walk")
+    walk_ctx = B.Context(scene, device=0)
+    monkeypatch.delenv("MIPT_TRAVERSAL")
+    cam = B.default_camera(160, 120)
+    o, d = wide_ctx.eye_rays(cam)
+    rng = np.random.default_rng(3)
+    o2 = rng.uniform(-1.2, 1.2, (30000, 3)).astype(np.float32)
+    d2 = rng.normal(size=(30000, 3)).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True).astype(np.float32)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    ref = orc.intersect(o, d)
+    for ctx in (wide_ctx, walk_ctx):
+        got = ctx.trace(o, d)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and \
+            np.array_equal(bits(got[2]), bits(ref[2]))
+        assert np.array_equal(ctx.occluded(o, d, 1e-4, 1.5), orc.occluded(o, d, 1e-4, 1.5))
+    # the two kernels do different amounts of box work for the same answer
+    wide_ctx.reset_stats(); wide_ctx.set_counting(True); wide_ctx.trace(o, d); a = wide_ctx.stats()
+    walk_ctx.reset_stats(); walk_ctx.set_counting(True); walk_ctx.trace(o, d); b = walk_ctx.stats()
+    assert a["tri_tests_closest"] == b["tri_tests_closest"]  # exactly the reference's triangle tests, either way
+    wide_ctx.set_counting(False); walk_ctx.set_counting(False)

@@ -223,3 +223,51 @@ def test_bench_scene_qualifies_for_exact_reciprocal(B, sf):
     assert sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT).exact_reciprocal
     arrays[0] = (np.asarray(arrays[0], np.float32) * np.float32(2.0 ** -70)).astype(np.float32)
     assert not sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT).exact_reciprocal
+
+
+def test_wide_tree_eligibility(B, sf):
+    """the order-free traversal is only used where its proof holds: boxes nested child-inside-parent, a proper
+    binary tree, tame planes.  The bench scene and every fixture qualify; a tree with one child box poking out of
+    its parent, or a threaded graph that is not a tree, must fall back to the literal walk (wide_nodes == 0) while
+    still being accepted (the links point forward, so the literal walk terminates)"""
+    assert sf.product_scene_from_mesh_arrays(*sf.sponza_standin(1), lights=sf.SPONZA_LIGHT).wide_nodes > 20000
+    arrays = sf.load_scene_arrays("cube")
+    mesh = B.Mesh.from_arrays(*arrays)
+    bvh = B.BVH(mesh)
+    lights = (B.Light * 1)()
+    good = B.SceneDesc()
+    B.check(B.lib().mipt_scene_desc_fill(mesh.h, bvh.h, None, lights, 1, C.byref(good)))
+    a = bvh.arrays()
+
+    def wide_nodes_with(field, arr):
+        d = B.SceneDesc()
+        C.pointer(d)[0] = good
+        keep = np.ascontiguousarray(arr)
+        setattr(d, field, keep.ctypes.data_as(type(getattr(d, field))))
+        out = C.c_void_p()
+        B.check(B.lib().mipt_scene_create(C.byref(d), C.byref(out)))
+        n = B.lib().mipt_scene_wide_nodes(out)
+        B.lib().mipt_scene_destroy(out)
+        return n
+
+    assert wide_nodes_with("node_min", a["node_min"]) > 0  # unchanged: qualifies
+    interior = np.flatnonzero(a["leaf_count"] == 0)
+    child = int(a["id_hit"][interior[0]])
+    bad = a["node_min"].copy(); bad[3 * child] -= 1.0  # the child's box now sticks out of its parent's
+    assert wide_nodes_with("node_min", bad) == 0
+    bad = a["node_max"].copy(); bad[3 * child + 1] += 0.5
+    assert wide_nodes_with("node_max", bad) == 0
+    # a forward-pointing threaded graph that is not a tree: a leaf's miss link skips its sibling subtree
+    leaf = int(np.flatnonzero(a["leaf_count"] > 0)[0])
+    if a["id_miss"][leaf] != 0 and a["id_miss"][a["id_miss"][leaf]] != 0:
+        bad_miss, bad_hit = a["id_miss"].copy(), a["id_hit"].copy()
+        bad_miss[leaf] = bad_hit[leaf] = a["id_miss"][a["id_miss"][leaf]]
+        d = B.SceneDesc()
+        C.pointer(d)[0] = good
+        k1, k2 = np.ascontiguousarray(bad_miss), np.ascontiguousarray(bad_hit)
+        d.id_miss = k1.ctypes.data_as(type(d.id_miss))
+        d.id_hit = k2.ctypes.data_as(type(d.id_hit))
+        out = C.c_void_p()
+        if B.lib().mipt_scene_create(C.byref(d), C.byref(out)) == 0:
+            assert B.lib().mipt_scene_wide_nodes(out) == 0
+            B.lib().mipt_scene_destroy(out)
