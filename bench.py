@@ -172,7 +172,11 @@ def main():
                          st["launches_closest"])
         ko = kernel_line(st["rays_occluded"], cnt["node_visits_occluded"], cnt["tri_tests_occluded"], st["ms_occluded"],
                          st["launches_occluded"])
-        dom, dom_name = (kc, "k_trace_closest") if st["ms_closest"] >= st["ms_occluded"] else (ko, "k_trace_occluded")
+        # the kernel behind the two traversal entries: the order-free 4-wide traversal when the scene qualifies
+        # (each launch is followed by a literal-walk launch over the handful of rays it handed back), else the walk
+        wide = scene.wide_nodes > 0 and os.environ.get("MIPT_TRAVERSAL") != "walk"
+        names = ("k_trace_wide_closest", "k_trace_wide_occluded") if wide else ("k_trace_closest", "k_trace_occluded")
+        dom, dom_name = (kc, names[0]) if st["ms_closest"] >= st["ms_occluded"] else (ko, names[1])
         traffic, valu_frac, l2_hit = None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
         if os.path.exists(tf):
@@ -197,14 +201,15 @@ def main():
                        "ms_per_frame_1spp": elapsed_max / args.steps * 1e3 / spp_per_step * world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom_name,
-                         "per_kernel": {"k_trace_closest": kc, "k_trace_occluded": ko,
+                         "per_kernel": {"k_trace_closest": kc, "k_trace_occluded": ko, "kernel_names": list(names),
                                         "other_ms_total": st["ms_other"], "other_launches": int(st["launches_other"])},
                          "valu_active_frac": valu_frac, "l2_hit_rate": l2_hit,
                          "note": "achieved = algorithmic bytes (48 B/ray + 32 B/node visit + 36 B/triangle test) per "
-                                 "launch / average launch duration from HIP events in the timed region (rank 0). The walk "
-                                 "re-reads a few MB of nodes from LDS/L1/L2, so algorithmic bytes exceed HBM traffic "
-                                 "(`traffic`, PMC) about tenfold and frac can exceed 1: the kernel is bound by vector-ALU "
-                                 "issue (valu_active_frac, PMC), not by HBM"},
+                                 "launch / average launch duration from HIP events in the timed region (rank 0); node "
+                                 "visits = box tests (4 per visit of a 4-wide node + the exact test of each candidate "
+                                 "leaf). The traversal re-reads a few MB of nodes from LDS/L1/L2, so algorithmic bytes "
+                                 "exceed HBM traffic (`traffic`, PMC) about tenfold and frac can exceed 1: the kernel is "
+                                 "bound by vector-ALU issue (valu_active_frac, PMC), not by HBM"},
         }
         if world == 1:
             # primary-only rate of configs[0] (cornellbox 512x512, closest-hit ids), reported beside the
