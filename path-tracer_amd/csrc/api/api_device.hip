@@ -122,6 +122,7 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s) {
                 s->leafBox.push_back(make_float4(d->node_min[3 * b + 2], d->node_max[3 * b + 2],
                                                  __builtin_bit_cast(float, d->leaf_first[b]), 0.0f));
                 for (int r = 0; r < 3; r++) s->leafBox.push_back(s->leafTris[(size_t)3 * d->leaf_first[b] + r]);  // its first triangle
+                s->leafBox.back().w = __builtin_bit_cast(float, d->leaf_first[b]);  // ... tagged with its leafTris index
                 nLeaves++;
             } else {
                 interiorMask |= 1 << k;

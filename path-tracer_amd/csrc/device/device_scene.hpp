@@ -19,7 +19,8 @@
 //             leaf of slot k = leafBase + popcount(leafMask & ((1 << k) - 1))
 //   leafBox   5 x float4 per leaf (wide leaf numbering): {min.x, max.x, min.y, max.y} {min.z, max.z, bits(first
 //             leaf triangle), 0} -- the leaf's exact box, tested with the reference's exact predicate -- followed by
-//             a copy of the leaf's first leafTris record, so that opening a leaf is ONE round trip to memory
+//             a copy of the leaf's first leafTris record (third float4's .w = bits(its leafTris index)), so that
+//             opening a leaf is ONE round trip to memory
 //   leafTris  3 x float4 per triangle reference (48 B), in leaf (triList) order:
 //               {p0.xyz, bits(original triangle id)}
 //               {p0-p1,  bits(1 if last triangle of its leaf)}

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     // leaf groups still to be opened (LIFO, g0 on top; order is free) and the open leaf's triangle cursor
     int groups = 0;
     unsigned g0 = 0, g1 = 0, g2 = 0, g3 = 0;
-    int cur = -1;
+    int cur = -1, curLeaf = 0;
     unsigned raySlot = 0, queueSlot = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
     int sx = 0, sy = 0, sz = 0;  // 1 where the direction component is negative
@@ -261,19 +261,17 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         const unsigned long long mStuck = mPend & ~mCanVisit;
         if (mPend != 0ull && (__popcll(mPend) >= PT_TUNE_WIDE_LEAF || __popcll(mStuck) >= PT_TUNE_WIDE_STUCK || mCanVisit == 0ull)) {
             do {
-                // One round trip per iteration: a lane either opens the next leaf of its top group (exact box +
-                // the leaf's first triangle, one 80-B record) or goes on with the next triangle of its open leaf.
+                // One round trip per iteration: a lane either opens the next leaf of its top group (the copy of the
+                // leaf's first triangle in its record) or goes on with the next triangle of its open leaf.  A
+                // candidate leaf counts only if its exact box passes the reference's predicate; "box passes AND
+                // triangle accepted" is evaluated triangle first, so the box test (and the load of the box) is paid
+                // only by the few lanes whose triangle would change the result.
                 const bool opening = cur < 0 && groups > 0;
-                const bool testing = cur >= 0 || opening;
-                if (testing) {
+                if (cur >= 0 || opening) {
                     const __attribute__((address_space(1))) float4v* triAt;
-                    float4v b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
                     if (opening) {
-                        const int leaf = group_take(g0);
-                        const __attribute__((address_space(1))) float4v* rec =
-                            (const __attribute__((address_space(1))) float4v*)s.leafBox + (size_t)kLeafRecF4 * (size_t)leaf;
-                        b0 = rec[0]; b1 = rec[1];
-                        triAt = rec + 2;
+                        curLeaf = group_take(g0);
+                        triAt = (const __attribute__((address_space(1))) float4v*)s.leafBox + (size_t)kLeafRecF4 * (size_t)curLeaf + 2;
                         if ((g0 & 15u) == 0u) {
                             g0 = g1; g1 = g2; g2 = g3;
                             --groups;
@@ -282,30 +280,30 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                         triAt = (const __attribute__((address_space(1))) float4v*)s.leafTris + 3 * (size_t)cur;
                     }
                     const float4v q0 = triAt[0], q1 = triAt[1], q2 = triAt[2];
-                    bool valid = true;
-                    if (opening) {
+                    if (opening) cur = f2i(q2.w);
+                    if (COUNT) nt++;
+                    float t, be, ga;
+                    bool acc = tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z},
+                                        vec3{ox, oy, oz}, vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
+                    // the reference keeps the FIRST of equal t's in depth-first order: smaller leafTris index wins
+                    acc = acc && (ANYHIT || t < bestT || (t == bestT && cur < bestSeq));
+                    bool boxMissed = false;
+                    if (acc) {  // rare: now the leaf must prove that the reference would have opened it
+                        const __attribute__((address_space(1))) float4v* rec =
+                            (const __attribute__((address_space(1))) float4v*)s.leafBox + (size_t)kLeafRecF4 * (size_t)curLeaf;
                         if (COUNT) nv++;
-                        valid = slab_hit_fast(b0, b1, ox, oy, oz, dx, dy, dz, yx, yy, yz);  // the reference's predicate
-                        cur = f2i(b1.z);
+                        boxMissed = !slab_hit_fast(rec[0], rec[1], ox, oy, oz, dx, dy, dz, yx, yy, yz);  // the reference's predicate
+                        acc = !boxMissed;
                     }
-                    if (valid) {  // one triangle (cs488.h:1671-1675 / 1693-1697)
-                        if (COUNT) nt++;
-                        float t, be, ga;
-                        const bool acc = tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z},
-                                                  vec3{ox, oy, oz}, vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
-                        // the reference keeps the FIRST of equal t's in depth-first order: smaller leafTris index wins
-                        if (acc && (ANYHIT || t < bestT || (t == bestT && cur < bestSeq))) {
-                            bestTri = f2i(q0.w); bestSeq = cur; bestT = t; bestB = be; bestG = ga;
-                        }
-                        if (ANYHIT && acc) {
-                            PT_FINISH();  // isHit: any accepted triangle decides
-                        } else if (f2i(q1.w)) {
-                            cur = -1;  // last triangle of this leaf
-                        } else {
-                            ++cur;
-                        }
+                    if (acc) {
+                        bestTri = f2i(q0.w); bestSeq = cur; bestT = t; bestB = be; bestG = ga;
+                    }
+                    if (ANYHIT && acc) {
+                        PT_FINISH();  // isHit: any accepted triangle decides
+                    } else if (boxMissed || f2i(q1.w)) {
+                        cur = -1;  // last triangle of this leaf, or a leaf the reference never opens
                     } else {
-                        cur = -1;  // the leaf's own box is missed: the reference does not test its triangles
+                        ++cur;
                     }
                 }
                 if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();

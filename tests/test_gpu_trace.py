@@ -224,8 +224,10 @@ def test_literal_walk_and_wide_traversal_agree(B, ob, sf, name, monkeypatch):
         assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and \
             np.array_equal(bits(got[2]), bits(ref[2]))
         assert np.array_equal(ctx.occluded(o, d, 1e-4, 1.5), orc.occluded(o, d, 1e-4, 1.5))
-    # the two kernels do different amounts of box work for the same answer
+    # the two kernels do different amounts of work for the same answer: the wide one tests the triangles of every
+    # CANDIDATE leaf (conservative test) and asks the exact box predicate only for triangles that would change the
+    # result, so it tests a few more triangles than the reference and far fewer boxes exactly
     wide_ctx.reset_stats(); wide_ctx.set_counting(True); wide_ctx.trace(o, d); a = wide_ctx.stats()
     walk_ctx.reset_stats(); walk_ctx.set_counting(True); walk_ctx.trace(o, d); b = walk_ctx.stats()
-    assert a["tri_tests_closest"] == b["tri_tests_closest"]  # exactly the reference's triangle tests, either way
+    assert b["tri_tests_closest"] <= a["tri_tests_closest"] <= 1.5 * b["tri_tests_closest"] + 16
     wide_ctx.set_counting(False); walk_ctx.set_counting(False)
