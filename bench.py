@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-primary", action="store_true",
+                    help="also time configs[0] (cornellbox 512x512 primary rays only); off by default so that the kernel "
+                         "averages of a rocprofv3 run of this command are those of the headline workload")
     ap.add_argument("--detail", type=int, default=1, help="sponza-standin tessellation (1: 65,536 tris, 2: 256,768)")
     args = ap.parse_args()
 
@@ -211,7 +214,7 @@ def main():
                                  "exceed HBM traffic (`traffic`, PMC) about tenfold and frac can exceed 1: the kernel is "
                                  "bound by vector-ALU issue (valu_active_frac, PMC), not by HBM"},
         }
-        if world == 1:
+        if world == 1 and args.with_primary:
             # primary-only rate of configs[0] (cornellbox 512x512, closest-hit ids), reported beside the
             # headline; 262,144 rays per frame cannot fill the chip, this is a latency figure
             try:

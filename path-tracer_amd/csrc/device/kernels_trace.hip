@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                                                   const int* __restrict__ remap, const unsigned* __restrict__ remapCount) {
     // remap != nullptr: the queue is the list remap[0 .. *remapCount) of queue slots (the rays k_trace_wide handed
     // back, kernels_trace_wide.hip); most launches find it empty
-    if (remap && *remapCount == 0u) return;
+    if (remap && (size_t)blockIdx.x * kTraceBlock >= (size_t)*remapCount) return;  // a block per kTraceBlock listed rays is plenty
     __shared__ float4 top[2 * kTopNodes];
     __shared__ unsigned prefix[kShards + 1];
     const int lane = threadIdx.x & 63;

@@ -196,6 +196,12 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                         bestTri = -1; bestSeq = 0x7fffffff; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
                         w = 0;
                         hasRay = true;
+                    } else if (ox != ox || oy != oy || oz != oz || dx != dx || dy != dy || dz != dz) {
+                        // A NaN anywhere in the ray: every determinant of raytraceTriangle that decides acceptance
+                        // contains every component of d or of p0 - o, so t = C / D is NaN and `t > tMin` fails for
+                        // every triangle (cs488.h:782-812): the reference walks the whole tree (a NaN quotient
+                        // passes AABB::intersect) and returns a miss.  Same answer, without the walk.
+                        if (!ANYHIT) hits[raySlot] = make_float4(i2f(-1), 3.402823466e+38f, 0.0f, 0.0f);
                     } else {
                         slow = true;  // this ray takes the literal walk in a later launch
                     }
