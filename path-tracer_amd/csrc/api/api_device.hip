@@ -47,7 +47,7 @@ struct mipt_scene {
     bool planesTame = true;  // see DevScene::planesTame
     int nTopNodes = 0;       // see DevScene::nTopNodes
     // 4-wide tree over the same leaves for the order-free traversal (device_scene.hpp "wide")
-    std::vector<float4> wnodes, leafBox;
+    std::vector<float4> wnodes, leafBox, leafHead;
     int nWide = 0;
     bool wideOk = false;
 };
@@ -121,8 +121,8 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s) {
                 s->leafBox.push_back(make_float4(d->node_min[3 * b], d->node_max[3 * b], d->node_min[3 * b + 1], d->node_max[3 * b + 1]));
                 s->leafBox.push_back(make_float4(d->node_min[3 * b + 2], d->node_max[3 * b + 2],
                                                  __builtin_bit_cast(float, d->leaf_first[b]), 0.0f));
-                for (int r = 0; r < 3; r++) s->leafBox.push_back(s->leafTris[(size_t)3 * d->leaf_first[b] + r]);  // its first triangle
-                s->leafBox.back().w = __builtin_bit_cast(float, d->leaf_first[b]);  // ... tagged with its leafTris index
+                for (int r = 0; r < 3; r++) s->leafHead.push_back(s->leafTris[(size_t)3 * d->leaf_first[b] + r]);  // its first triangle
+                s->leafHead.back().w = __builtin_bit_cast(float, d->leaf_first[b]);  // ... tagged with its leafTris index
                 nLeaves++;
             } else {
                 interiorMask |= 1 << k;
@@ -389,7 +389,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         for (char cv : covered)
             if (!cv) { delete s; return fail(MIPT_ERR_INVALID, "tri_index entry not owned by any leaf"); }
         s->wideOk = build_wide(d, s);
-        if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->nWide = 0; }
+        if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear(); s->nWide = 0; }
         // textures -> one byte pool
         std::vector<int> texOfs((size_t)d->n_textures, 0);
         for (int i = 0; i < d->n_textures; i++) {
@@ -466,7 +466,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t szLights = align256(s->lights.size() * sizeof(float4) + 16);
     const size_t szWide = align256(s->wnodes.size() * sizeof(float4) + 16);
     const size_t szLeafBox = align256(s->leafBox.size() * sizeof(float4) + 16);
-    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights + szWide + szLeafBox;
+    const size_t szLeafHead = align256(s->leafHead.size() * sizeof(float4) + 16);
+    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights + szWide + szLeafBox + szLeafHead;
     std::vector<unsigned char> stage(total, 0);
     size_t o = 0;
     const size_t oNodes = o; memcpy(&stage[o], s->nodes.data(), s->nodes.size() * sizeof(float4)); o += szNodes;
@@ -477,7 +478,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t oEnv = o; if (!s->env.empty()) memcpy(&stage[o], s->env.data(), s->env.size() * sizeof(float)); o += szEnv;
     const size_t oLights = o; if (!s->lights.empty()) memcpy(&stage[o], s->lights.data(), s->lights.size() * sizeof(float4)); o += szLights;
     const size_t oWide = o; if (!s->wnodes.empty()) memcpy(&stage[o], s->wnodes.data(), s->wnodes.size() * sizeof(float4)); o += szWide;
-    const size_t oLeafBox = o; if (!s->leafBox.empty()) memcpy(&stage[o], s->leafBox.data(), s->leafBox.size() * sizeof(float4));
+    const size_t oLeafBox = o; if (!s->leafBox.empty()) memcpy(&stage[o], s->leafBox.data(), s->leafBox.size() * sizeof(float4)); o += szLeafBox;
+    const size_t oLeafHead = o; if (!s->leafHead.empty()) memcpy(&stage[o], s->leafHead.data(), s->leafHead.size() * sizeof(float4));
     if (hipMalloc(&c->arena, total) != hipSuccess) { mipt_context_destroy(c); return fail(MIPT_ERR_DEVICE, "hipMalloc(arena) failed"); }
     c->arenaBytes = total;
     if (hipMemcpy(c->arena, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
@@ -498,6 +500,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.nTopNodes = s->nTopNodes;
     c->ds.wnodes = (const float4*)(base + oWide);
     c->ds.leafBox = (const float4*)(base + oLeafBox);
+    c->ds.leafHead = (const float4*)(base + oLeafHead);
     c->ds.nWide = s->wideOk ? s->nWide : 0;
     c->ds.nWideTop = s->nWide < ptd::kWideTopNodes ? s->nWide : ptd::kWideTopNodes;
     if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||

@@ -17,10 +17,11 @@
 //               {bits(childBase), bits(leafBase), bits(interiorMask | leafMask << 4), 0}
 //             interior child of slot k = childBase + popcount(interiorMask & ((1 << k) - 1)),
 //             leaf of slot k = leafBase + popcount(leafMask & ((1 << k) - 1))
-//   leafBox   5 x float4 per leaf (wide leaf numbering): {min.x, max.x, min.y, max.y} {min.z, max.z, bits(first
-//             leaf triangle), 0} -- the leaf's exact box, tested with the reference's exact predicate -- followed by
-//             a copy of the leaf's first leafTris record (third float4's .w = bits(its leafTris index)), so that
-//             opening a leaf is ONE round trip to memory
+//   leafHead  3 x float4 per leaf (wide leaf numbering): a copy of the leaf's first leafTris record (third float4's
+//             .w = bits(its leafTris index)), so that opening a leaf is ONE round trip to memory
+//   leafBox   2 x float4 per leaf (wide leaf numbering): {min.x, max.x, min.y, max.y} {min.z, max.z, bits(first
+//             leaf triangle), 0} -- the leaf's exact box for the reference's exact predicate; read only for the
+//             few triangles that would change a ray's result, hence apart from leafHead
 //   leafTris  3 x float4 per triangle reference (48 B), in leaf (triList) order:
 //               {p0.xyz, bits(original triangle id)}
 //               {p0-p1,  bits(1 if last triangle of its leaf)}
@@ -53,6 +54,7 @@ struct DevScene {
     int nNodes, nLeafTris, nTris, nMaterials, envW, envH, nLights;
     const float4* wnodes;   // 4-wide nodes (nWide == 0: the scene does not qualify, every ray takes the literal walk)
     const float4* leafBox;
+    const float4* leafHead;
     int nWide, nWideTop;    // wide nodes [0, nWideTop) are kept in LDS by k_trace_wide
     int nTopNodes;   // nodes [0, nTopNodes) are the top of the tree, numbered first so that k_trace can hold them in LDS
     int planesTame;  // every box plane is 0 or has magnitude in [2^-61, 2^40] and min <= max: the exact reciprocal slab division may be used (traverse.hpp)
@@ -73,7 +75,6 @@ constexpr int kTraceBlock = PT_TUNE_BLOCK;  // k_trace: 16 wavefronts per block,
 #define PT_TUNE_GRID 512
 #endif
 constexpr int kWideNodeF4 = 7;      // float4 per wide node
-constexpr int kLeafRecF4 = 5;       // float4 per leafBox record
 constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's per-lane stack can hold (binary depth 32)
 #ifndef PT_TUNE_WIDE_BLOCK
 #define PT_TUNE_WIDE_BLOCK 1024

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     const __attribute__((address_space(1))) float4v* triAt;
                     if (opening) {
                         curLeaf = group_take(g0);
-                        triAt = (const __attribute__((address_space(1))) float4v*)s.leafBox + (size_t)kLeafRecF4 * (size_t)curLeaf + 2;
+                        triAt = (const __attribute__((address_space(1))) float4v*)s.leafHead + 3 * (size_t)curLeaf;
                         if ((g0 & 15u) == 0u) {
                             g0 = g1; g1 = g2; g2 = g3;
                             --groups;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     bool boxMissed = false;
                     if (acc) {  // rare: now the leaf must prove that the reference would have opened it
                         const __attribute__((address_space(1))) float4v* rec =
-                            (const __attribute__((address_space(1))) float4v*)s.leafBox + (size_t)kLeafRecF4 * (size_t)curLeaf;
+                            (const __attribute__((address_space(1))) float4v*)s.leafBox + 2 * (size_t)curLeaf;
                         if (COUNT) nv++;
                         boxMissed = !slab_hit_fast(rec[0], rec[1], ox, oy, oz, dx, dy, dz, yx, yy, yz);  // the reference's predicate
                         acc = !boxMissed;
