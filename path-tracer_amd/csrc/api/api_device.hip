@@ -58,8 +58,9 @@ struct mipt_scene {
 // first (they are the ones k_trace_wide keeps in LDS); the leaves get ids of our own, again consecutive per wide
 // node (leafBase + ordinal).  Returns false, leaving the scene on the literal walk, when the input is not the
 // properly nested binary tree the order-free traversal relies on (see kernels_trace.hip) or exceeds its limits.
-static bool build_wide(const mipt_scene_desc* d, mipt_scene* s) {
+static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greedy) {
     const int n = d->n_nodes;
+    s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear();
     if (!s->planesTame) return false;
     auto isLeaf = [&](int i) { return d->leaf_count[i] > 0; };
     std::vector<int> left((size_t)n, -1), right((size_t)n, -1);
@@ -90,6 +91,25 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s) {
         int sl[4] = {-1, -1, -1, -1}, ns = 0;
         if (isLeaf(b)) {
             sl[ns++] = b;  // a tree that is one leaf: the root wide node has that leaf as its only slot
+        } else if (greedy) {
+            // open the slot with the largest box (the one most rays pierce) until the four slots are taken
+            sl[ns++] = left[b]; sl[ns++] = right[b];
+            while (ns < 4) {
+                int pick = -1;
+                double best = -1.0;
+                for (int k = 0; k < ns; k++) {
+                    if (isLeaf(sl[k])) continue;
+                    const double ex = (double)d->node_max[3 * sl[k]] - d->node_min[3 * sl[k]];
+                    const double ey = (double)d->node_max[3 * sl[k] + 1] - d->node_min[3 * sl[k] + 1];
+                    const double ez = (double)d->node_max[3 * sl[k] + 2] - d->node_min[3 * sl[k] + 2];
+                    const double area = ex * ey + ey * ez + ez * ex;
+                    if (area > best) { best = area; pick = k; }
+                }
+                if (pick < 0) break;
+                const int c = sl[pick];
+                sl[pick] = left[c];
+                sl[ns++] = right[c];
+            }
         } else {
             for (const int c : {left[b], right[b]}) {
                 if (isLeaf(c)) sl[ns++] = c;
@@ -388,7 +408,9 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         }
         for (char cv : covered)
             if (!cv) { delete s; return fail(MIPT_ERR_INVALID, "tri_index entry not owned by any leaf"); }
-        s->wideOk = build_wide(d, s);
+        // slots by largest box first; a tree that this makes deeper than the kernel's stacks falls back to plain grandchildren
+        const char* collapse = getenv("MIPT_WIDE_COLLAPSE");  // "pairs": grandchildren only (for comparisons)
+        s->wideOk = (!(collapse && !strcmp(collapse, "pairs")) && build_wide(d, s, true)) || build_wide(d, s, false);
         if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear(); s->nWide = 0; }
         // textures -> one byte pool
         std::vector<int> texOfs((size_t)d->n_textures, 0);

@@ -89,6 +89,9 @@ __device__ __forceinline__ int group_take(unsigned& e) {  // removes the lowest 
     return (int)(e >> 8) + __popc((e >> 4) & 15u & (bit - 1u));
 }
 
+#ifndef PT_DIAG_UTIL
+#define PT_DIAG_UTIL 0  // diagnostic builds only: 1 / 2 turn the counters into lanes-active / lanes-issued of the visit / leaf phase
+#endif
 #define PT_WIDE_ATTR __attribute__((amdgpu_waves_per_eu(PT_TUNE_WIDE_WAVES, PT_TUNE_WIDE_WAVES)))
 
 template <bool ANYHIT, bool COUNT>
@@ -221,6 +224,9 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         // ---- visits: lanes with a node to visit and room for one more leaf group ----
 #pragma unroll
         for (int b = 0; b < PT_TUNE_WIDE_BURST; b++) {
+#if PT_DIAG_UTIL == 1
+            if (COUNT) { const unsigned long long ma = __ballot(w >= 0 && groups < kWideGroups); if (ma) { nv += (w >= 0 && groups < kWideGroups) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; } }
+#endif
             if (w >= 0 && groups < kWideGroups) {
                 float4v nearx, farx, neary, fary, nearz, farz, meta;  // rows picked by the direction signs (sx, sy, sz)
                 if (w < nTop) {  // top of the tree: from LDS
@@ -235,7 +241,9 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                 }
                 const int masks = f2i(meta.z);
                 const int imask = masks & 15, lmask = (masks >> 4) & 15;
+#if !PT_DIAG_UTIL
                 if (COUNT) nv += (unsigned)__popc((unsigned)(imask | lmask));
+#endif
                 const int hm = wide_hit_mask(nearx, farx, neary, fary, nearz, farz, ox, oy, oz, yx, yy, yz);
                 const int lh = hm & lmask, ih = hm & imask;
                 if (lh != 0) {  // park the candidate leaves of this node as one group
@@ -273,6 +281,9 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                 // triangle accepted" is evaluated triangle first, so the box test (and the load of the box) is paid
                 // only by the few lanes whose triangle would change the result.
                 const bool opening = cur < 0 && groups > 0;
+#if PT_DIAG_UTIL == 2
+                if (COUNT) { nv += (cur >= 0 || opening) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; }
+#endif
                 if (cur >= 0 || opening) {
                     const __attribute__((address_space(1))) float4v* triAt;
                     if (opening) {
@@ -287,7 +298,9 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     }
                     const float4v q0 = triAt[0], q1 = triAt[1], q2 = triAt[2];
                     if (opening) cur = f2i(q2.w);
+#if !PT_DIAG_UTIL
                     if (COUNT) nt++;
+#endif
                     float t, be, ga;
                     bool acc = tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z},
                                         vec3{ox, oy, oz}, vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
@@ -297,7 +310,9 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     if (acc) {  // rare: now the leaf must prove that the reference would have opened it
                         const __attribute__((address_space(1))) float4v* rec =
                             (const __attribute__((address_space(1))) float4v*)s.leafBox + 2 * (size_t)curLeaf;
+#if !PT_DIAG_UTIL
                         if (COUNT) nv++;
+#endif
                         boxMissed = !slab_hit_fast(rec[0], rec[1], ox, oy, oz, dx, dy, dz, yx, yy, yz);  // the reference's predicate
                         acc = !boxMissed;
                     }

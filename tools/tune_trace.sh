@@ -32,5 +32,7 @@ elif [ "$1" = bench ]; then
 import json, sys
 d = json.load(open(sys.argv[2])); pk = d["roofline"]["per_kernel"]
 print(f'{sys.argv[1]:28s} {d["value"]:8.1f} Mrays/s  step {d["ms_per_step"]:7.2f} ms  closest {pk["k_trace_closest"]["avg_launch_ms"]:6.3f}  occluded {pk["k_trace_occluded"]["avg_launch_ms"]:6.3f}')
+for k in ("k_trace_closest", "k_trace_occluded"):  # counters per ray (their meaning changes in -DPT_DIAG_UTIL builds)
+    print(f'    {k:18s} counter0/ray {pk[k]["node_visits_per_ray"]:9.3f}  counter1/ray {pk[k]["tri_tests_per_ray"]:9.3f}')
 PY
 fi
