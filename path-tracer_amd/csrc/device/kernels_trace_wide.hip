@@ -251,24 +251,21 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     g0 = pack_group(f2i(meta.y), lmask, lh);
                     ++groups;
                 }
-                if (ih != 0) {  // go down into the first hit child, keep the others as one stack entry
-                    unsigned e = pack_group(f2i(meta.x), imask, ih);
-                    w = group_take(e);
-                    if ((e & 15u) != 0u) {
-                        if (tos != 0u) { stack[sp] = tos; sp += kWideBlock; }
-                        tos = e;
-                    }
-                } else if (tos != 0u) {  // nothing below: on to the pending child nearest on the stack
+                if (ih != 0) {  // the hit children go on top of the stack as one entry
+                    if (tos != 0u) { stack[sp] = tos; sp += kWideBlock; }
+                    tos = pack_group(f2i(meta.x), imask, ih);
+                }
+                w = -1;
+                if (tos != 0u) {  // next: the lowest pending child of the top entry
                     w = group_take(tos);
                     if ((tos & 15u) == 0u) {
-                        if (sp > 0) { sp -= kWideBlock; tos = stack[sp]; } else tos = 0u;
+                        tos = 0u;
+                        if (sp > 0) { sp -= kWideBlock; tos = stack[sp]; }
                     }
-                } else {
-                    w = -1;
-                    if (groups == 0 && cur < 0) PT_FINISH();
                 }
             }
         }
+        if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();  // walked everything, nothing parked
         // ---- leaves: open parked leaves with the exact box test, test their triangles ----
         const unsigned long long mCanVisit = __ballot(w >= 0 && groups < kWideGroups);
         unsigned long long mPend = __ballot(cur >= 0 || groups > 0);
