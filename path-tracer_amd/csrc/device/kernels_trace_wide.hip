@@ -56,8 +56,11 @@ constexpr int kWideGroups = 4;  // leaf groups a lane may hold (one group = the 
 // satisfy |q~ - q| <= 2^-22 |q| (three roundings of 2^-24 each), q~ and q have the same sign and vanish together.
 // L(x) = x - 2^-21|x| and U(x) = x + 2^-21|x| are increasing, L(q~) <= q <= U(q~), and min/max commute with
 // increasing maps, so t1 >= L(t1~), t2 <= U(t2~); the exact predicate max(t1, 0) <= t2 therefore implies
-// max(L(t1~), 0) <= U(t2~).  The code widens by 2^-20, which also covers the rounding of its own two
-// multiplications (for t1~ < 0 the clamp makes the shape of L irrelevant, for t2~ < 0 both forms reject).
+// max(L(t1~), 0) <= U(t2~).  The code widens by more than that and does it once per ray instead of once per slot:
+// near planes are multiplied by yn = RN(y (1 - 2^-19)), far planes by yf = RN(y (1 + 2^-19)), so a positive near
+// quotient comes out below (s/d)(1 - 2^-19)(1 + 2^-24)^3 < (s/d)(1 - 2^-24) <= q and a positive far quotient above
+// q; a negative near quotient stays negative (the clamp at 0 makes its size irrelevant) and a negative far
+// quotient stays negative (both forms reject).  No product underflows: fast_div_ok bounds the magnitudes.
 // nearx .. farz: the node's plane rows already picked by the ray's direction signs (min row where d > 0, max row
 // where d < 0 for "near", the other one for "far"): the products are monotone in the plane, so these ARE
 // min / max of the two candidates, without computing both.
@@ -66,15 +69,19 @@ constexpr int kWideGroups = 4;  // leaf groups a lane may hold (one group = the 
 // scene, those rays visit thousands of nodes and the launch waits for them: measured 20 % slower, not kept.)
 __device__ __forceinline__ int wide_hit_mask(const float4v nearx, const float4v farx, const float4v neary, const float4v fary,
                                              const float4v nearz, const float4v farz, const float ox, const float oy,
-                                             const float oz, const float yx, const float yy, const float yz) {
-    const float4v nx = (nearx - ox) * yx, fx = (farx - ox) * yx;
-    const float4v ny = (neary - oy) * yy, fy = (fary - oy) * yy;
-    const float4v nz = (nearz - oz) * yz, fz = (farz - oz) * yz;
-    const float4v t1 = __builtin_elementwise_max(__builtin_elementwise_max(nx, ny), nz);
-    const float4v t2 = __builtin_elementwise_min(__builtin_elementwise_min(fx, fy), fz);
-    const float4v u = __builtin_elementwise_max(t1 * 0x1.ffffep-1f, (float4v)(0.0f));  // 1 - 2^-20
-    const float4v v = t2 * 0x1.00001p0f;                                               // 1 + 2^-20
-    return (!(u.x > v.x) ? 1 : 0) | (!(u.y > v.y) ? 2 : 0) | (!(u.z > v.z) ? 4 : 0) | (!(u.w > v.w) ? 8 : 0);
+                                             const float oz, const float2v ynx, const float2v yny, const float2v ynz,
+                                             const float2v yfx, const float2v yfy, const float2v yfz) {
+    // yn* = RN(y (1 - 2^-19)), yf* = RN(y (1 + 2^-19)), both lanes of a pair equal: the factors of L above, folded into
+    // the reciprocals once per ray (three roundings of 2^-24 each leave more than the 2^-20 the argument needs)
+    const float4v sx0 = nearx - ox, sx1 = farx - ox, sy0 = neary - oy, sy1 = fary - oy, sz0 = nearz - oz, sz1 = farz - oz;
+    const float2v nxa = sx0.xy * ynx, nxb = sx0.zw * ynx, fxa = sx1.xy * yfx, fxb = sx1.zw * yfx;
+    const float2v nya = sy0.xy * yny, nyb = sy0.zw * yny, fya = sy1.xy * yfy, fyb = sy1.zw * yfy;
+    const float2v nza = sz0.xy * ynz, nzb = sz0.zw * ynz, fza = sz1.xy * yfz, fzb = sz1.zw * yfz;
+    const float u0 = fmaxf(fmaxf(fmaxf(nxa.x, nya.x), nza.x), 0.0f), v0 = fminf(fminf(fxa.x, fya.x), fza.x);
+    const float u1 = fmaxf(fmaxf(fmaxf(nxa.y, nya.y), nza.y), 0.0f), v1 = fminf(fminf(fxa.y, fya.y), fza.y);
+    const float u2 = fmaxf(fmaxf(fmaxf(nxb.x, nyb.x), nzb.x), 0.0f), v2 = fminf(fminf(fxb.x, fyb.x), fzb.x);
+    const float u3 = fmaxf(fmaxf(fmaxf(nxb.y, nyb.y), nzb.y), 0.0f), v3 = fminf(fminf(fxb.y, fyb.y), fzb.y);
+    return (!(u0 > v0) ? 1 : 0) | (!(u1 > v1) ? 2 : 0) | (!(u2 > v2) ? 4 : 0) | (!(u3 > v3) ? 8 : 0);
 }
 
 // entry of the per-lane stacks: base << 8 | kindMask << 4 | pendingMask (pending != 0, so an entry is never 0);
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     unsigned raySlot = 0, queueSlot = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
     int sx = 0, sy = 0, sz = 0;  // 1 where the direction component is negative
+    float2v ynx = {0, 0}, yny = {0, 0}, ynz = {0, 0}, yfx = {0, 0}, yfy = {0, 0}, yfz = {0, 0};  // y shrunk / grown, see wide_hit_mask
     float tMin = 0.0f, tMax = 0.0f;
     int bestTri = -1, bestSeq = 0x7fffffff;
     float bestT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;
@@ -195,6 +203,8 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
                     if (fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz})) {
                         yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
+                        ynx = (float2v)(yx * 0x1.ffffcp-1f); yny = (float2v)(yy * 0x1.ffffcp-1f); ynz = (float2v)(yz * 0x1.ffffcp-1f);
+                        yfx = (float2v)(yx * 0x1.00002p0f); yfy = (float2v)(yy * 0x1.00002p0f); yfz = (float2v)(yz * 0x1.00002p0f);
                         sx = dx < 0.0f ? 1 : 0; sy = dy < 0.0f ? 1 : 0; sz = dz < 0.0f ? 1 : 0;
                         bestTri = -1; bestSeq = 0x7fffffff; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
                         w = 0;
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
 #if !PT_DIAG_UTIL
                 if (COUNT) nv += (unsigned)__popc((unsigned)(imask | lmask));
 #endif
-                const int hm = wide_hit_mask(nearx, farx, neary, fary, nearz, farz, ox, oy, oz, yx, yy, yz);
+                const int hm = wide_hit_mask(nearx, farx, neary, fary, nearz, farz, ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz);
                 const int lh = hm & lmask, ih = hm & imask;
                 if (lh != 0) {  // park the candidate leaves of this node as one group
                     g3 = g2; g2 = g1; g1 = g0;
