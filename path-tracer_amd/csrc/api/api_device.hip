@@ -48,6 +48,7 @@ struct mipt_scene {
     int nTopNodes = 0;       // see DevScene::nTopNodes
     // 4-wide tree over the same leaves for the order-free traversal (device_scene.hpp "wide")
     std::vector<float4> wnodes, leafBox, leafHead;
+    std::vector<int> nodeRight;
     int nWide = 0;
     bool wideOk = false;
 };
@@ -271,7 +272,8 @@ void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView 
     if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
         unsigned* sl = (unsigned*)c->slow.p;
         launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, sl, (int*)(sl + 2));
-        launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, sl + 1, hits, cnt, (const int*)(sl + 2), sl);
+        launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, (const int*)(sl + 2), sl);  // short list: a wavefront per ray
+        launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, sl + 1, hits, cnt, (const int*)(sl + 2), sl);  // long list: a lane per ray
     } else {
         launch_trace_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt);
     }
@@ -287,6 +289,7 @@ void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueVie
     if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
         unsigned* sl = (unsigned*)c->slow.p;
         launch_trace_wide_occluded(c->stream, c->ds, rays, target, q, cursor, occ, cnt, sl, (int*)(sl + 2));
+        launch_trace_slow_occluded(c->stream, c->ds, rays, target, occ, cnt, (const int*)(sl + 2), sl);
         launch_trace_occluded(c->stream, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, sl + 1, occ, cnt, (const int*)(sl + 2), sl);
     } else {
         launch_trace_occluded(c->stream, c->ds, rays, target, q, cursor, occ, cnt);
@@ -412,6 +415,11 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         const char* collapse = getenv("MIPT_WIDE_COLLAPSE");  // "pairs": grandchildren only (for comparisons)
         s->wideOk = (!(collapse && !strcmp(collapse, "pairs")) && build_wide(d, s, true)) || build_wide(d, s, false);
         if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear(); s->nWide = 0; }
+        if (s->wideOk) {  // build_wide has verified the binary tree: right child = where the left subtree's walk exits
+            s->nodeRight.assign((size_t)n, 0);
+            for (int i = 0; i < n; i++)
+                if (d->leaf_count[i] == 0) s->nodeRight[(size_t)perm[i]] = perm[d->id_miss[d->id_hit[i]]];
+        }
         // textures -> one byte pool
         std::vector<int> texOfs((size_t)d->n_textures, 0);
         for (int i = 0; i < d->n_textures; i++) {
@@ -489,7 +497,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t szWide = align256(s->wnodes.size() * sizeof(float4) + 16);
     const size_t szLeafBox = align256(s->leafBox.size() * sizeof(float4) + 16);
     const size_t szLeafHead = align256(s->leafHead.size() * sizeof(float4) + 16);
-    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights + szWide + szLeafBox + szLeafHead;
+    const size_t szRight = align256(s->nodeRight.size() * sizeof(int) + 16);
+    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights + szWide + szLeafBox + szLeafHead + szRight;
     std::vector<unsigned char> stage(total, 0);
     size_t o = 0;
     const size_t oNodes = o; memcpy(&stage[o], s->nodes.data(), s->nodes.size() * sizeof(float4)); o += szNodes;
@@ -501,7 +510,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t oLights = o; if (!s->lights.empty()) memcpy(&stage[o], s->lights.data(), s->lights.size() * sizeof(float4)); o += szLights;
     const size_t oWide = o; if (!s->wnodes.empty()) memcpy(&stage[o], s->wnodes.data(), s->wnodes.size() * sizeof(float4)); o += szWide;
     const size_t oLeafBox = o; if (!s->leafBox.empty()) memcpy(&stage[o], s->leafBox.data(), s->leafBox.size() * sizeof(float4)); o += szLeafBox;
-    const size_t oLeafHead = o; if (!s->leafHead.empty()) memcpy(&stage[o], s->leafHead.data(), s->leafHead.size() * sizeof(float4));
+    const size_t oLeafHead = o; if (!s->leafHead.empty()) memcpy(&stage[o], s->leafHead.data(), s->leafHead.size() * sizeof(float4)); o += szLeafHead;
+    const size_t oRight = o; if (!s->nodeRight.empty()) memcpy(&stage[o], s->nodeRight.data(), s->nodeRight.size() * sizeof(int));
     if (hipMalloc(&c->arena, total) != hipSuccess) { mipt_context_destroy(c); return fail(MIPT_ERR_DEVICE, "hipMalloc(arena) failed"); }
     c->arenaBytes = total;
     if (hipMemcpy(c->arena, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
@@ -523,6 +533,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.wnodes = (const float4*)(base + oWide);
     c->ds.leafBox = (const float4*)(base + oLeafBox);
     c->ds.leafHead = (const float4*)(base + oLeafHead);
+    c->ds.nodeRight = (const int*)(base + oRight);
     c->ds.nWide = s->wideOk ? s->nWide : 0;
     c->ds.nWideTop = s->nWide < ptd::kWideTopNodes ? s->nWide : ptd::kWideTopNodes;
     if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||

@@ -93,6 +93,10 @@ void launch_trace_wide_closest(hipStream_t st, const DevScene& s, const float4* 
 void launch_trace_wide_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
                                 unsigned* cursor, unsigned char* occ, unsigned long long* counters, unsigned* slowCount,
                                 int* slowList);
+void launch_trace_slow_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, float4* hits,
+                               unsigned long long* counters, const int* list, const unsigned* listCount);
+void launch_trace_slow_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, unsigned char* occ,
+                                unsigned long long* counters, const int* list, const unsigned* listCount);
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays);
 void launch_resolve_hits(hipStream_t st, const DevScene& s, const float4* rays, const float4* hits, size_t n,
                          float* out);

@@ -73,6 +73,10 @@ constexpr int kPendAnyHit = PT_TUNE_PEND_ANYHIT;  // any-hit rays end at their f
 #define PT_TUNE_WAVES_PER_EU 8
 #endif
 #define PT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(PT_TUNE_WAVES_PER_EU, PT_TUNE_WAVES_PER_EU)))
+constexpr unsigned kSlowMaxRays = 8192;  // lists up to this long go to k_trace_slow, longer ones to k_trace
+constexpr int kSlowStack = 8192;         // node stack of one k_trace_slow wavefront (32 KB of LDS)
+constexpr int kSlowReserve = 256;        // ... of which this much is kept free for one-node-at-a-time steps
+
 template <bool ANYHIT, bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s, const float4* __restrict__ rays,
                                                   const int* __restrict__ index, const int* __restrict__ target,
@@ -82,7 +86,8 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                                                   const int* __restrict__ remap, const unsigned* __restrict__ remapCount) {
     // remap != nullptr: the queue is the list remap[0 .. *remapCount) of queue slots (the rays k_trace_wide handed
     // back, kernels_trace_wide.hip); most launches find it empty
-    if (remap && (size_t)blockIdx.x * kTraceBlock >= (size_t)*remapCount) return;  // a block per kTraceBlock listed rays is plenty
+    // (short lists belong to k_trace_slow below: a wavefront per ray instead of a lane per ray)
+    if (remap && (*remapCount <= kSlowMaxRays || (size_t)blockIdx.x * kTraceBlock >= (size_t)*remapCount)) return;  // a block per kTraceBlock listed rays is plenty
     __shared__ float4 top[2 * kTopNodes];
     __shared__ unsigned prefix[kShards + 1];
     const int lane = threadIdx.x & 63;
@@ -377,6 +382,111 @@ void launch_divcheck(hipStream_t st, unsigned seed, unsigned blocks, unsigned pe
     hipLaunchKernelGGL(k_divcheck, dim3(blocks), dim3(kBlock), 0, st, seed, perThread, mismatches);
 }
 
+// The handful of rays per launch that k_trace_wide hands back (a direction component that is exactly zero, mostly)
+// would each keep ONE lane of k_trace walking for a millisecond while the chip waits.  k_trace_slow gives every such
+// ray a whole wavefront instead: the threaded walk (cs488.h:1661-1705) visits a node exactly when its parent's box was
+// hit, so the wavefront keeps a stack of nodes still to be visited, pops up to 64 of them at a time, tests their boxes
+// with the reference's IEEE predicate (NaN quotients included: nothing here relies on nesting), pushes both children
+// of every interior node that was hit and tests the triangles of every leaf that was hit.  Visit order is not the
+// walk's, so ties in t go to the smaller leafTris index, which IS the walk's order (as in k_trace_wide).  Only for
+// trees that build_wide has verified (s.nodeRight exists only then).  The stack cannot overflow: above
+// kSlowStack - kSlowReserve entries a step pops one node, which is a plain depth-first walk and adds at most one
+// entry per level (binary depth <= 3 * kWideMaxDepth < kSlowReserve - 128).
+template <bool ANYHIT, bool COUNT>
+__global__ __launch_bounds__(64) void k_trace_slow(DevScene s, const float4* __restrict__ rays, const int* __restrict__ index,
+                                                   const int* __restrict__ target, float4* __restrict__ hits,
+                                                   unsigned char* __restrict__ occ, unsigned long long* __restrict__ counters,
+                                                   const int* __restrict__ list, const unsigned* __restrict__ listCount) {
+    __shared__ int stack[kSlowStack];
+    const unsigned n = *listCount;
+    if (n > kSlowMaxRays) return;  // k_trace takes long lists
+    const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const __attribute__((address_space(1))) float4v* nodesGlobal = (const __attribute__((address_space(1))) float4v*)s.nodes;
+    const __attribute__((address_space(1))) float4v* trisGlobal = (const __attribute__((address_space(1))) float4v*)s.leafTris;
+    unsigned nv = 0, nt = 0;
+    for (unsigned r = blockIdx.x; r < n; r += gridDim.x) {
+        const unsigned slot = (unsigned)list[r];
+        const unsigned raySlot = index ? (unsigned)index[slot] : slot;
+        const size_t rs = ANYHIT ? (size_t)slot : (size_t)raySlot;  // shadow rays live in queue order
+        const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
+        const vec3 o{r0.x, r0.y, r0.z}, d{r1.x, r1.y, r1.z};
+        const float tMin = r0.w, tMax = r1.w;
+        int bestTri = -1, bestSeq = 0x7fffffff;
+        float bestT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;
+        int top = 1;
+        if (lane == 0) stack[0] = 0;
+        __syncthreads();
+        while (top > 0) {
+            const int take = top > kSlowStack - kSlowReserve ? 1 : (top < 64 ? top : 64);
+            int node = -1;
+            if (lane < take) node = stack[top - 1 - lane];
+            top -= take;
+            __syncthreads();  // every pop is done before a push reuses its slot
+            int left = 0, right = 0;
+            if (node >= 0) {
+                const float4v n0 = nodesGlobal[2 * (size_t)node], n1 = nodesGlobal[2 * (size_t)node + 1];
+                if (COUNT) nv++;
+                if (slab_hit_ieee(n0, n1, o, d)) {
+                    const int link = f2i(n1.w);
+                    if (link > 0) {
+                        left = link;
+                        right = s.nodeRight[node];
+                    } else {
+                        for (int cur = ~link;; ++cur) {  // the leaf's triangles (cs488.h:1671-1675)
+                            const float4v q0 = trisGlobal[3 * (size_t)cur], q1 = trisGlobal[3 * (size_t)cur + 1],
+                                          q2 = trisGlobal[3 * (size_t)cur + 2];
+                            if (COUNT) nt++;
+                            float t, be, ga;
+                            if (tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z}, o, d, tMin, tMax,
+                                         t, be, ga) &&
+                                (t < bestT || (t == bestT && cur < bestSeq))) {
+                                bestTri = f2i(q0.w); bestSeq = cur; bestT = t; bestB = be; bestG = ga;
+                            }
+                            if (f2i(q1.w)) break;
+                        }
+                    }
+                }
+            }
+            if (ANYHIT && __ballot(bestTri >= 0) != 0ull) break;  // isHit: any accepted triangle decides
+            const unsigned long long mPush = __ballot(left > 0);
+            if (left > 0) {
+                const int at = top + 2 * __popcll(mPush & below);
+                stack[at] = right;
+                stack[at + 1] = left;
+            }
+            top += 2 * __popcll(mPush);
+            __syncthreads();
+        }
+        // the wavefront's answer: smallest t, ties to the smaller leafTris index
+        for (int off = 32; off > 0; off >>= 1) {
+            const float t2 = __shfl_down(bestT, off), b2 = __shfl_down(bestB, off), g2 = __shfl_down(bestG, off);
+            const int tri2 = __shfl_down(bestTri, off), seq2 = __shfl_down(bestSeq, off);
+            if (tri2 >= 0 && (bestTri < 0 || t2 < bestT || (t2 == bestT && seq2 < bestSeq))) {
+                bestTri = tri2; bestSeq = seq2; bestT = t2; bestB = b2; bestG = g2;
+            }
+        }
+        if (lane == 0) {
+            if (ANYHIT) {
+                if (bestTri >= 0) occ[target ? (unsigned)target[slot] : slot] = 1;
+            } else {
+                hits[raySlot] = make_float4(i2f(bestTri), bestT, bestB, bestG);
+            }
+        }
+        __syncthreads();
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) {
+            nv += __shfl_down(nv, off);
+            nt += __shfl_down(nt, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], (unsigned long long)nv);
+            atomicAdd(&counters[1], (unsigned long long)nt);
+        }
+    }
+}
+
 // ---- launchers ----
 static inline unsigned grid_for(size_t n) {
     size_t g = (n + kBlock - 1) / kBlock;
@@ -413,6 +523,21 @@ void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays
     else
         hipLaunchKernelGGL((k_trace<true, false>), dim3(g), dim3(kTraceBlock), 0, st, s, rays, nullptr, target, q, cursor,
                            nullptr, occ, counters, remap, remapCount);
+}
+// the rays list[0 .. *listCount) (queue slots), a wavefront each; a no-op for lists longer than kSlowMaxRays
+void launch_trace_slow_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, float4* hits,
+                               unsigned long long* counters, const int* list, const unsigned* listCount) {
+    if (counters)
+        hipLaunchKernelGGL((k_trace_slow<false, true>), dim3(1024), dim3(64), 0, st, s, rays, index, nullptr, hits, nullptr, counters, list, listCount);
+    else
+        hipLaunchKernelGGL((k_trace_slow<false, false>), dim3(1024), dim3(64), 0, st, s, rays, index, nullptr, hits, nullptr, counters, list, listCount);
+}
+void launch_trace_slow_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, unsigned char* occ,
+                                unsigned long long* counters, const int* list, const unsigned* listCount) {
+    if (counters)
+        hipLaunchKernelGGL((k_trace_slow<true, true>), dim3(1024), dim3(64), 0, st, s, rays, nullptr, target, nullptr, occ, counters, list, listCount);
+    else
+        hipLaunchKernelGGL((k_trace_slow<true, false>), dim3(1024), dim3(64), 0, st, s, rays, nullptr, target, nullptr, occ, counters, list, listCount);
 }
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays) {
     hipLaunchKernelGGL(k_eye_rays, dim3(grid_for(count)), dim3(kBlock), 0, st, cam, first, (unsigned)count, rays);

@@ -168,14 +168,16 @@ def test_scene_outside_reciprocal_preconditions_takes_ieee_path(B, ob, sf):
             np.array_equal(bits(a[2]), bits(b[2])), variant
 
 
-def test_rays_straddling_reciprocal_preconditions(B, ob, sf):
+@pytest.mark.parametrize("n", [1 << 14, 1 << 16])
+def test_rays_straddling_reciprocal_preconditions(B, ob, sf, n):
     """per-ray choice between the reciprocal and the IEEE slab division: directions and origins with components
     at, just inside and just outside the precondition bounds (2^-40 / 2^40 for d, 2^-61 / 2^40 for o), zeros,
-    denormals -- all in one batch so that lanes of one wavefront mix both code paths"""
+    denormals -- all in one batch so that lanes of one wavefront mix both code paths.  The rays the wide traversal
+    hands back go to k_trace_slow (a wavefront per ray) when they are few (n = 2^14: about 6,000) and to the literal
+    k_trace (a lane per ray) when they are more than 8,192 (n = 2^16)"""
     scene, ctx, orc = setup_scene(B, sf, "sponza-standin-trace")
     assert scene.exact_reciprocal
     rng = np.random.default_rng(11)
-    n = 1 << 14
     o = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32) * np.float32(0.5) + np.array([0, 1.0, 0], np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
@@ -196,6 +198,27 @@ def test_rays_straddling_reciprocal_preconditions(B, ob, sf):
     assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[2]), bits(b[2]))
     occ = ctx.occluded(o, d, 1e-4, 2.5)
     assert np.array_equal(occ, orc.occluded(o, d, 1e-4, 2.5))
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "sponza-standin-trace"])
+def test_axis_parallel_rays_from_vertices(B, ob, sf, name):
+    """rays along the axes that start AT mesh vertices: two direction components are exactly zero and the origin
+    lies in box planes, so AABB::intersect (cs488.h:571-608) sees (p - o) / 0 = NaN and +-inf quotients -- a child box
+    can pass where its parent fails.  These rays leave the order-free traversal and take k_trace_slow, which
+    must follow the reference's parent-hit rule literally"""
+    scene, ctx, orc = setup_scene(B, sf, name)
+    pos = (sf.sponza_standin(1) if name.startswith("sponza") else sf.load_scene_arrays(name))[0]
+    verts = np.asarray(pos, np.float32).reshape(-1, 3)
+    rng = np.random.default_rng(5)
+    n = 6000
+    o = verts[rng.integers(0, len(verts), n)].copy()
+    axes = np.eye(3, dtype=np.float32)
+    d = axes[rng.integers(0, 3, n)] * rng.choice(np.array([-1, 1], np.float32), n)[:, None]
+    a = ctx.trace(o, d)
+    b = orc.intersect(o, d)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[2]), bits(b[2]))
+    for tmin, tmax in ((0.0, 3.0e38), (1e-4, 2.5)):
+        assert np.array_equal(ctx.occluded(o, d, tmin, tmax), orc.occluded(o, d, tmin, tmax))
 
 
 @pytest.mark.parametrize("name", ["cornellbox", "teapot-glass", "testObj"])
