@@ -54,9 +54,10 @@ struct mipt_scene {
 };
 
 // Builds the 4-wide node array from the threaded binary tree: a wide node stands for a binary interior node, its (up
-// to 4) slots are that node's grandchildren, a child that is a leaf taking one slot itself.  Wide nodes are numbered
-// breadth-first, so the interior children of a node are consecutive (childBase + ordinal) and the top levels come
-// first (they are the ones k_trace_wide keeps in LDS); the leaves get ids of our own, again consecutive per wide
+// to 4) slots are that node's grandchildren, a child that is a leaf taking one slot itself (or, by default, the
+// result of opening the largest box until four slots are taken).  Wide nodes are numbered in the order their
+// parents are opened, largest box first, so the interior children of a node are consecutive (childBase + ordinal)
+// and the nodes met most often come first (they are the ones k_trace_wide keeps in LDS); the leaves get ids of our own, again consecutive per wide
 // node (leafBase + ordinal).  Returns false, leaving the scene on the literal walk, when the input is not the
 // properly nested binary tree the order-free traversal relies on (see kernels_trace.hip) or exceeds its limits.
 static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greedy) {
@@ -82,12 +83,24 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
     }
     for (int i = 0; i < n; i++)
         if (!seen[i]) return false;
-    struct W { int bnode, depth; };
-    std::vector<W> wide;  // breadth-first
+    struct W { int bnode, depth, childBase; };
+    std::vector<W> wide;  // in id order
     std::vector<int> slotsOf;  // 4 per wide node: binary node of the slot or -1
-    wide.push_back({0, 0});
+    wide.push_back({0, 0, 0});
     int nLeaves = 0;
-    for (size_t w = 0; w < wide.size(); w++) {
+    auto boxArea = [&](int b) -> double {
+        const double ex = (double)d->node_max[3 * b] - d->node_min[3 * b], ey = (double)d->node_max[3 * b + 1] - d->node_min[3 * b + 1],
+                     ez = (double)d->node_max[3 * b + 2] - d->node_min[3 * b + 2];
+        return ex * ey + ey * ez + ez * ex;
+    };
+    // Nodes are opened largest box first and the children of a node get the next free ids, so that the ids below
+    // kWideTopNodes (the ones k_trace_wide keeps in LDS) are the nodes rays meet most often -- on a balanced tree this
+    // is breadth-first order -- while the children of a node stay consecutive.
+    std::priority_queue<std::pair<double, int>> open;
+    open.push({boxArea(0), 0});
+    while (!open.empty()) {
+        const size_t w = (size_t)open.top().second;
+        open.pop();
         const int b = wide[w].bnode;
         int sl[4] = {-1, -1, -1, -1}, ns = 0;
         if (isLeaf(b)) {
@@ -117,20 +130,26 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
                 else { sl[ns++] = left[c]; sl[ns++] = right[c]; }
             }
         }
+        if (slotsOf.size() < 4 * wide.size()) slotsOf.resize(4 * wide.size(), -1);
+        wide[w].childBase = (int)wide.size();
         for (int k = 0; k < 4; k++) {
-            slotsOf.push_back(sl[k]);
-            if (sl[k] >= 0 && !isLeaf(sl[k])) wide.push_back({sl[k], wide[w].depth + 1});
+            slotsOf[4 * w + k] = sl[k];
+            if (sl[k] >= 0 && !isLeaf(sl[k])) {
+                open.push({boxArea(sl[k]), (int)wide.size()});
+                wide.push_back({sl[k], wide[w].depth + 1, 0});
+            }
         }
         if (wide[w].depth >= ptd::kWideMaxDepth) return false;
         if (wide.size() >= ((size_t)1 << 22)) return false;
     }
     const int nw = (int)wide.size();
+    slotsOf.resize((size_t)4 * nw, -1);
     s->wnodes.assign((size_t)ptd::kWideNodeF4 * nw, make_float4(0, 0, 0, 0));
-    // second pass: records (children of wide node w start at childBase, in the order the first pass appended them)
+    // second pass: records (children of wide node w start at its childBase, in the order the first pass appended them)
     int nextChild = 1;
     for (int w = 0; w < nw; w++) {
         const int* sl = &slotsOf[(size_t)4 * w];
-        int interiorMask = 0, leafMask = 0, childBase = nextChild, leafBase = nLeaves;
+        int interiorMask = 0, leafMask = 0, childBase = wide[w].childBase, leafBase = nLeaves;
         float lo[3][4], hi[3][4];
         for (int k = 0; k < 4; k++) {
             const int src = sl[k] >= 0 ? sl[k] : sl[0];  // an empty slot repeats slot 0's (tame) box; the masks leave it out

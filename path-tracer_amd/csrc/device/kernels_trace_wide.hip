@@ -49,6 +49,15 @@ namespace ptd {
 #ifndef PT_TUNE_WIDE_STUCK
 #define PT_TUNE_WIDE_STUCK 8
 #endif
+#ifndef PT_TUNE_WIDE_LEAF_ANYHIT
+#define PT_TUNE_WIDE_LEAF_ANYHIT PT_TUNE_WIDE_LEAF
+#endif
+#ifndef PT_TUNE_WIDE_KEEP_ANYHIT
+#define PT_TUNE_WIDE_KEEP_ANYHIT PT_TUNE_WIDE_KEEP
+#endif
+#ifndef PT_TUNE_WIDE_STUCK_ANYHIT
+#define PT_TUNE_WIDE_STUCK_ANYHIT PT_TUNE_WIDE_STUCK
+#endif
 constexpr int kWideBlock = PT_TUNE_WIDE_BLOCK;
 constexpr int kWideGroups = 4;  // leaf groups a lane may hold (one group = the leaf slots of one wide node)
 
@@ -280,7 +289,8 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         const unsigned long long mCanVisit = __ballot(w >= 0 && groups < kWideGroups);
         unsigned long long mPend = __ballot(cur >= 0 || groups > 0);
         const unsigned long long mStuck = mPend & ~mCanVisit;
-        if (mPend != 0ull && (__popcll(mPend) >= PT_TUNE_WIDE_LEAF || __popcll(mStuck) >= PT_TUNE_WIDE_STUCK || mCanVisit == 0ull)) {
+        if (mPend != 0ull && (__popcll(mPend) >= (ANYHIT ? PT_TUNE_WIDE_LEAF_ANYHIT : PT_TUNE_WIDE_LEAF) ||
+                              __popcll(mStuck) >= (ANYHIT ? PT_TUNE_WIDE_STUCK_ANYHIT : PT_TUNE_WIDE_STUCK) || mCanVisit == 0ull)) {
             do {
                 // One round trip per iteration: a lane either opens the next leaf of its top group (the copy of the
                 // leaf's first triangle in its record) or goes on with the next triangle of its open leaf.  A
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                 }
                 if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();
                 mPend = __ballot(cur >= 0 || groups > 0);
-            } while (__popcll(mPend) >= PT_TUNE_WIDE_KEEP);
+            } while (__popcll(mPend) >= (ANYHIT ? PT_TUNE_WIDE_KEEP_ANYHIT : PT_TUNE_WIDE_KEEP));
         }
     }
 #undef PT_FINISH
