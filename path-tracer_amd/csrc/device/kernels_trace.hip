@@ -73,7 +73,8 @@ constexpr int kPendAnyHit = PT_TUNE_PEND_ANYHIT;  // any-hit rays end at their f
 #define PT_TUNE_WAVES_PER_EU 8
 #endif
 #define PT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(PT_TUNE_WAVES_PER_EU, PT_TUNE_WAVES_PER_EU)))
-constexpr unsigned kSlowMaxRays = 8192;  // lists up to this long go to k_trace_slow, longer ones to k_trace
+constexpr unsigned kSlowMaxRays = 4096;  // lists up to this long go to k_trace_slow, longer ones to k_trace
+constexpr int kSlowGrid = 256;           // wavefronts of k_trace_slow (an idle launch costs a few microseconds per 256)
 constexpr int kSlowStack = 8192;         // node stack of one k_trace_slow wavefront (32 KB of LDS)
 constexpr int kSlowReserve = 256;        // ... of which this much is kept free for one-node-at-a-time steps
 
@@ -528,16 +529,16 @@ void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays
 void launch_trace_slow_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, float4* hits,
                                unsigned long long* counters, const int* list, const unsigned* listCount) {
     if (counters)
-        hipLaunchKernelGGL((k_trace_slow<false, true>), dim3(1024), dim3(64), 0, st, s, rays, index, nullptr, hits, nullptr, counters, list, listCount);
+        hipLaunchKernelGGL((k_trace_slow<false, true>), dim3(kSlowGrid), dim3(64), 0, st, s, rays, index, nullptr, hits, nullptr, counters, list, listCount);
     else
-        hipLaunchKernelGGL((k_trace_slow<false, false>), dim3(1024), dim3(64), 0, st, s, rays, index, nullptr, hits, nullptr, counters, list, listCount);
+        hipLaunchKernelGGL((k_trace_slow<false, false>), dim3(kSlowGrid), dim3(64), 0, st, s, rays, index, nullptr, hits, nullptr, counters, list, listCount);
 }
 void launch_trace_slow_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, unsigned char* occ,
                                 unsigned long long* counters, const int* list, const unsigned* listCount) {
     if (counters)
-        hipLaunchKernelGGL((k_trace_slow<true, true>), dim3(1024), dim3(64), 0, st, s, rays, nullptr, target, nullptr, occ, counters, list, listCount);
+        hipLaunchKernelGGL((k_trace_slow<true, true>), dim3(kSlowGrid), dim3(64), 0, st, s, rays, nullptr, target, nullptr, occ, counters, list, listCount);
     else
-        hipLaunchKernelGGL((k_trace_slow<true, false>), dim3(1024), dim3(64), 0, st, s, rays, nullptr, target, nullptr, occ, counters, list, listCount);
+        hipLaunchKernelGGL((k_trace_slow<true, false>), dim3(kSlowGrid), dim3(64), 0, st, s, rays, nullptr, target, nullptr, occ, counters, list, listCount);
 }
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays) {
     hipLaunchKernelGGL(k_eye_rays, dim3(grid_for(count)), dim3(kBlock), 0, st, cam, first, (unsigned)count, rays);

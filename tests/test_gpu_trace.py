@@ -168,13 +168,13 @@ def test_scene_outside_reciprocal_preconditions_takes_ieee_path(B, ob, sf):
             np.array_equal(bits(a[2]), bits(b[2])), variant
 
 
-@pytest.mark.parametrize("n", [1 << 14, 1 << 16])
+@pytest.mark.parametrize("n", [1 << 13, 1 << 16])
 def test_rays_straddling_reciprocal_preconditions(B, ob, sf, n):
     """per-ray choice between the reciprocal and the IEEE slab division: directions and origins with components
     at, just inside and just outside the precondition bounds (2^-40 / 2^40 for d, 2^-61 / 2^40 for o), zeros,
     denormals -- all in one batch so that lanes of one wavefront mix both code paths.  The rays the wide traversal
-    hands back go to k_trace_slow (a wavefront per ray) when they are few (n = 2^14: about 6,000) and to the literal
-    k_trace (a lane per ray) when they are more than 8,192 (n = 2^16)"""
+    hands back go to k_trace_slow (a wavefront per ray) when they are few (n = 2^13: about 3,000) and to the literal
+    k_trace (a lane per ray) when they are more than 4,096 (n = 2^16)"""
     scene, ctx, orc = setup_scene(B, sf, "sponza-standin-trace")
     assert scene.exact_reciprocal
     rng = np.random.default_rng(11)
@@ -210,7 +210,7 @@ def test_axis_parallel_rays_from_vertices(B, ob, sf, name):
     pos = (sf.sponza_standin(1) if name.startswith("sponza") else sf.load_scene_arrays(name))[0]
     verts = np.asarray(pos, np.float32).reshape(-1, 3)
     rng = np.random.default_rng(5)
-    n = 6000
+    n = 3000  # at most 4,096 handed-back rays go to k_trace_slow
     o = verts[rng.integers(0, len(verts), n)].copy()
     axes = np.eye(3, dtype=np.float32)
     d = axes[rng.integers(0, 3, n)] * rng.choice(np.array([-1, 1], np.float32), n)[:, None]
