@@ -206,6 +206,14 @@ const int32_t* mipt_bvh_id_sibling(const mipt_bvh*);
 const int32_t* mipt_bvh_tri_index(const mipt_bvh*);
 void mipt_bvh_destroy(mipt_bvh*);
 
+/* Flat binary cache of a loaded mesh and its built BVH.  The reference has no counterpart: it
+ * re-parses the .obj (TriangleMesh::load C:835-923) and re-runs the SAH build (BVH::build C:1562-1595) at every
+ * start.  save writes one file (magic, endianness probe, FNV-1a checksum, counted arrays); load returns a mesh and
+ * a bvh equal, array for array, to the ones that were saved, or MIPT_ERR_IO if the file is missing, truncated,
+ * corrupted or from an incompatible machine.  Array CONTENT is validated where it is used (mipt_scene_create). */
+int mipt_scene_cache_save(const char* path, const mipt_mesh* mesh, const mipt_bvh* bvh);
+int mipt_scene_cache_load(const char* path, mipt_mesh** mesh_out, mipt_bvh** bvh_out);
+
 /* Scene::addObject / addLight / background + preCalc, C:2020-2036: fills a
  * mipt_scene_desc that points INTO mesh, bvh and env (keep them alive while
  * the desc is used).  env may be NULL. */

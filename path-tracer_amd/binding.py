@@ -72,6 +72,7 @@ SYMBOLS = [
     "mipt_mesh_texcoords", "mipt_mesh_material_ids", "mipt_mesh_materials", "mipt_mesh_textures", "mipt_mesh_destroy",
     "mipt_image_load", "mipt_image_create", "mipt_image_width", "mipt_image_height", "mipt_image_pixels",
     "mipt_image_save_png", "mipt_image_save_hdr", "mipt_image_save_pfm", "mipt_image_destroy",
+    "mipt_scene_cache_save", "mipt_scene_cache_load",
     "mipt_bvh_build", "mipt_bvh_num_nodes", "mipt_bvh_num_leaves", "mipt_bvh_depth", "mipt_bvh_max_leaf_size",
     "mipt_bvh_node_min", "mipt_bvh_node_max", "mipt_bvh_id_hit", "mipt_bvh_id_miss", "mipt_bvh_leaf_first",
     "mipt_bvh_leaf_count", "mipt_bvh_id_left", "mipt_bvh_id_right", "mipt_bvh_id_parent", "mipt_bvh_id_sibling",
@@ -133,6 +134,8 @@ def lib():
     for n in ("mipt_image_save_png", "mipt_image_save_hdr", "mipt_image_save_pfm"):
         getattr(L, n).argtypes = [C.c_char_p, C.c_int32, C.c_int32, fp]
     L.mipt_bvh_build.argtypes = [vp, C.POINTER(vp)]
+    L.mipt_scene_cache_save.argtypes = [C.c_char_p, vp, vp]
+    L.mipt_scene_cache_load.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(vp)]
     L.mipt_scene_exact_reciprocal.argtypes = [vp]
     L.mipt_scene_exact_reciprocal.restype = C.c_int32
     L.mipt_scene_wide_nodes.argtypes = [vp]
@@ -349,11 +352,12 @@ def save_pfm(path, rgb):
 class BVH:
     """StacklessBVH of the reference (C:1641-1660) behind mipt_bvh_*"""
 
-    def __init__(self, mesh):
+    def __init__(self, mesh, handle=None):
         self.mesh = mesh
-        h = C.c_void_p()
-        check(lib().mipt_bvh_build(mesh.h, C.byref(h)))
-        self.h = h
+        if handle is None:
+            handle = C.c_void_p()
+            check(lib().mipt_bvh_build(mesh.h, C.byref(handle)))
+        self.h = handle
 
     @property
     def num_nodes(self):
@@ -384,6 +388,19 @@ class BVH:
         if getattr(self, "h", None) and _lib is not None:
             _lib.mipt_bvh_destroy(self.h)
             self.h = None
+
+
+def save_scene_cache(path, mesh, bvh):
+    """flat binary cache of a loaded mesh and its built BVH (mipt_scene_cache_save)"""
+    check(lib().mipt_scene_cache_save(os.fsencode(path), mesh.h, bvh.h))
+
+
+def load_scene_cache(path):
+    """-> (Mesh, BVH) as they were saved; raises on a missing, truncated or corrupted file"""
+    mh, bh = C.c_void_p(), C.c_void_p()
+    check(lib().mipt_scene_cache_load(os.fsencode(path), C.byref(mh), C.byref(bh)))
+    mesh = Mesh(mh)
+    return mesh, BVH(mesh, bh)
 
 
 class Scene:

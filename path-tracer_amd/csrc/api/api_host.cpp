@@ -202,6 +202,25 @@ const int32_t* mipt_bvh_id_sibling(const mipt_bvh* b) { return b ? b->bvh.idSibl
 const int32_t* mipt_bvh_tri_index(const mipt_bvh* b) { return b ? b->bvh.triIndex.data() : nullptr; }
 void mipt_bvh_destroy(mipt_bvh* b) { delete b; }
 
+int mipt_scene_cache_save(const char* path, const mipt_mesh* mesh, const mipt_bvh* bvh) {
+    if (!path || !mesh || !bvh) { pt::set_error("mipt_scene_cache_save: null argument"); return MIPT_ERR_INVALID; }
+    MIPT_GUARD_BEGIN
+    return pt::saveSceneCache(path, mesh->mesh, bvh->bvh);
+    MIPT_GUARD_END
+}
+int mipt_scene_cache_load(const char* path, mipt_mesh** mesh_out, mipt_bvh** bvh_out) {
+    if (!path || !mesh_out || !bvh_out) { pt::set_error("mipt_scene_cache_load: null argument"); return MIPT_ERR_INVALID; }
+    MIPT_GUARD_BEGIN
+    mipt_mesh* m = new mipt_mesh();
+    mipt_bvh* b = new mipt_bvh();
+    const int rc = pt::loadSceneCache(path, m->mesh, b->bvh);
+    if (rc != MIPT_OK) { delete m; delete b; return rc; }
+    *mesh_out = m;
+    *bvh_out = b;
+    return MIPT_OK;
+    MIPT_GUARD_END
+}
+
 int mipt_scene_desc_fill(const mipt_mesh* mesh, const mipt_bvh* bvh, const mipt_image* env, const mipt_light* lights,
                          int32_t n_lights, mipt_scene_desc* out) {
     if (!mesh || !bvh || !out || n_lights < 0 || (n_lights && !lights)) {

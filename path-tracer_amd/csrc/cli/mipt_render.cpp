@@ -7,6 +7,8 @@
 //               [--mode primary|direct|path] [--spp 16] [--bounces 4] [--seed 1]
 //               [--eye x y z] [--lookat x y z] [--light x y z w] [--device 0]
 //               [--out image.png] [--out-hdr image.hdr] [--out-pfm image.pfm]
+//               [--cache scene.miptsc]   mesh + BVH from this flat file when it exists and loads, else parsed and
+//                                        built as usual and then written to it (mipt_scene_cache_*)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +24,7 @@ static void die(const char* what) {
 }
 
 int main(int argc, char** argv) {
-    std::string scenePath, envPath, outPng, outHdr, outPfm;
+    std::string scenePath, envPath, outPng, outHdr, outPfm, cachePath;
     mipt_camera cam{};
     cam.width = 512; cam.height = 384;  // globalWidth / globalHeight, cs488.h:45-46
     cam.eye[2] = 1.5f;                  // cs488.h:81-83
@@ -47,6 +49,7 @@ int main(int argc, char** argv) {
         else if (a == "--out") { need(1); outPng = argv[++i]; }
         else if (a == "--out-hdr") { need(1); outHdr = argv[++i]; }
         else if (a == "--out-pfm") { need(1); outPfm = argv[++i]; }
+        else if (a == "--cache") { need(1); cachePath = argv[++i]; }
         else if (a == "--mode") {
             need(1);
             std::string m = argv[++i];
@@ -61,20 +64,32 @@ int main(int argc, char** argv) {
         } else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     mipt_mesh* mesh = nullptr;
-    if (scenePath.empty() || mipt_mesh_load_obj(scenePath.c_str(), &mesh) != MIPT_OK) {
-        // main.cpp:40-44: fall back to the single triangle when the .obj does not load
-        fprintf(stderr, "Invalid .obj file (%s).\nMaking a single triangle instead.\n", mipt_last_error());
-        if (mipt_mesh_create_single_triangle(&mesh) != MIPT_OK) die("single triangle");
+    mipt_bvh* bvh = nullptr;
+    auto t0 = std::chrono::high_resolution_clock::now();
+    const bool cached = !cachePath.empty() && mipt_scene_cache_load(cachePath.c_str(), &mesh, &bvh) == MIPT_OK;
+    if (cached) {
+        printf("Loaded cache \"%s\" with %d triangles (%.1f ms).\n", cachePath.c_str(), mipt_mesh_num_triangles(mesh),
+               std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count());
+    } else {
+        if (scenePath.empty() || mipt_mesh_load_obj(scenePath.c_str(), &mesh) != MIPT_OK) {
+            // main.cpp:40-44: fall back to the single triangle when the .obj does not load
+            fprintf(stderr, "Invalid .obj file (%s).\nMaking a single triangle instead.\n", mipt_last_error());
+            if (mipt_mesh_create_single_triangle(&mesh) != MIPT_OK) die("single triangle");
+        }
+        printf("Loaded \"%s\" with %d triangles (%.1f ms).\n", scenePath.c_str(), mipt_mesh_num_triangles(mesh),
+               std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count());
     }
-    printf("Loaded \"%s\" with %d triangles.\n", scenePath.c_str(), mipt_mesh_num_triangles(mesh));
     mipt_image* env = nullptr;
     if (!envPath.empty() && mipt_image_load(envPath.c_str(), &env) != MIPT_OK) die("environment");
-    auto t0 = std::chrono::high_resolution_clock::now();
-    mipt_bvh* bvh = nullptr;
-    if (mipt_bvh_build(mesh, &bvh) != MIPT_OK) die("BVH build");
-    auto t1 = std::chrono::high_resolution_clock::now();
-    printf("Built BVH: %d nodes, %d leaves, depth %d (%.1f ms)\n", mipt_bvh_num_nodes(bvh), mipt_bvh_num_leaves(bvh),
-           mipt_bvh_depth(bvh), std::chrono::duration<double, std::milli>(t1 - t0).count());
+    if (!cached) {
+        t0 = std::chrono::high_resolution_clock::now();
+        if (mipt_bvh_build(mesh, &bvh) != MIPT_OK) die("BVH build");
+        auto t1 = std::chrono::high_resolution_clock::now();
+        printf("Built BVH: %d nodes, %d leaves, depth %d (%.1f ms)\n", mipt_bvh_num_nodes(bvh), mipt_bvh_num_leaves(bvh),
+               mipt_bvh_depth(bvh), std::chrono::duration<double, std::milli>(t1 - t0).count());
+        if (!cachePath.empty() && mipt_scene_cache_save(cachePath.c_str(), mesh, bvh) != MIPT_OK)
+            fprintf(stderr, "mipt_render: cache not written: %s\n", mipt_last_error());
+    }
     mipt_scene_desc desc;
     if (mipt_scene_desc_fill(mesh, bvh, env, &light, 1, &desc) != MIPT_OK) die("scene description");
     mipt_scene* scene = nullptr;

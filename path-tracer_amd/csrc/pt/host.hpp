@@ -81,4 +81,8 @@ public:
     int build(const TriangleMesh* mesh);
 };
 
+// flat binary cache of a loaded mesh + built BVH (host/scene_cache.cpp)
+int saveSceneCache(const char* path, const TriangleMesh& mesh, const StacklessBVH& bvh);
+int loadSceneCache(const char* path, TriangleMesh& mesh, StacklessBVH& bvh);
+
 }  // namespace pt

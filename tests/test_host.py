@@ -271,3 +271,28 @@ def test_wide_tree_eligibility(B, sf):
         if B.lib().mipt_scene_create(C.byref(d), C.byref(out)) == 0:
             assert B.lib().mipt_scene_wide_nodes(out) == 0
             B.lib().mipt_scene_destroy(out)
+
+
+def test_scene_cache_round_trip_and_rejects_damage(B, tmp_path):
+    """the flat cache returns the mesh and the BVH array for array (so the scene built from it is the
+    one built from the .obj), and a truncated, bit-flipped or foreign file is refused"""
+    mesh = B.Mesh.load(os.path.join(MEDIA, "cornellbox.obj")) if os.path.isdir(MEDIA) else B.Mesh.single_triangle()
+    bvh = B.BVH(mesh)
+    path = str(tmp_path / "scene.miptsc")
+    B.save_scene_cache(path, mesh, bvh)
+    mesh2, bvh2 = B.load_scene_cache(path)
+    for f in ("positions", "normals", "texcoords", "material_ids"):
+        assert np.array_equal(getattr(mesh, f)().view(np.uint32), getattr(mesh2, f)().view(np.uint32)), f
+    assert mesh.materials() == mesh2.materials()
+    assert all(np.array_equal(a, b) for a, b in zip(mesh.textures(), mesh2.textures())) and len(mesh.textures()) == len(mesh2.textures())
+    a, b = bvh.arrays(), bvh2.arrays()
+    assert a.keys() == b.keys() and all(np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)) for k in a)
+    assert (bvh.num_nodes, bvh.num_leaves, bvh.depth, bvh.max_leaf_size) == (bvh2.num_nodes, bvh2.num_leaves, bvh2.depth, bvh2.max_leaf_size)
+    blob = open(path, "rb").read()
+    bad = str(tmp_path / "bad.miptsc")
+    for damaged in (blob[:len(blob) // 2], blob[:100] + bytes([blob[100] ^ 1]) + blob[101:], b"OBJ " + blob[4:], b""):
+        open(bad, "wb").write(damaged)
+        with pytest.raises(B.MiptError):
+            B.load_scene_cache(bad)
+    with pytest.raises(B.MiptError):
+        B.load_scene_cache(str(tmp_path / "missing.miptsc"))
