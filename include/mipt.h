@@ -183,6 +183,12 @@ int mipt_image_save_png(const char* path, int32_t width, int32_t height, const f
 /* float output for RMSE checks (not in the reference): Radiance .hdr and .pfm */
 int mipt_image_save_hdr(const char* path, int32_t width, int32_t height, const float* rgb);
 int mipt_image_save_pfm(const char* path, int32_t width, int32_t height, const float* rgb);
+/* One channel of Image::save (C:223-236): (unsigned char)(255.0f * gammaCorrection(toneMapping(v))), gamma 1.0,
+ * for n_values floats in the order given (no flip); mipt_image_save_png uses the same conversion. */
+int mipt_image_pack_rgb8(const float* rgb, size_t n_values, uint8_t* out);
+/* RMSE over all channels and the two means, accumulated in double (convergence curves of config 5,
+ * image parity tolerances); any output may be NULL.  No counterpart in the reference. */
+int mipt_image_compare(const float* a, const float* b, size_t n_values, double* rmse, double* mean_a, double* mean_b);
 void mipt_image_destroy(mipt_image*);
 
 /* TriangleMesh::preCalc C:817-831 + BVH::build C:1562-1595 (SAH split
@@ -281,6 +287,10 @@ int mipt_render(mipt_ctx* ctx, const mipt_camera* cam, const mipt_render_params*
  * frame readback of the reference, G:3213-3216, becomes mipt_buffer_download).
  * All on the context's device; upload/download/zero are ordered on its stream
  * and download synchronises. */
+/* mipt_image_pack_rgb8 on the device, asynchronous on the context's stream: the frame leaves the GPU (readback,
+ * or the tile gather to rank 0) as 3 bytes per pixel instead of 12.  Same bytes as the host conversion.
+ * rgb_dev 16-byte aligned, out_dev 4-byte aligned (any hipMalloc / torch allocation is). */
+int mipt_pack_rgb8_device(mipt_ctx* ctx, const float* rgb_dev, size_t n_values, uint8_t* out_dev);
 int mipt_buffer_alloc(mipt_ctx* ctx, size_t bytes, void** dev_ptr);
 int mipt_buffer_free(mipt_ctx* ctx, void* dev_ptr);
 int mipt_buffer_zero(mipt_ctx* ctx, void* dev_ptr, size_t bytes);

@@ -72,7 +72,7 @@ SYMBOLS = [
     "mipt_mesh_texcoords", "mipt_mesh_material_ids", "mipt_mesh_materials", "mipt_mesh_textures", "mipt_mesh_destroy",
     "mipt_image_load", "mipt_image_create", "mipt_image_width", "mipt_image_height", "mipt_image_pixels",
     "mipt_image_save_png", "mipt_image_save_hdr", "mipt_image_save_pfm", "mipt_image_destroy",
-    "mipt_scene_cache_save", "mipt_scene_cache_load",
+    "mipt_scene_cache_save", "mipt_scene_cache_load", "mipt_image_pack_rgb8", "mipt_image_compare", "mipt_pack_rgb8_device",
     "mipt_bvh_build", "mipt_bvh_num_nodes", "mipt_bvh_num_leaves", "mipt_bvh_depth", "mipt_bvh_max_leaf_size",
     "mipt_bvh_node_min", "mipt_bvh_node_max", "mipt_bvh_id_hit", "mipt_bvh_id_miss", "mipt_bvh_leaf_first",
     "mipt_bvh_leaf_count", "mipt_bvh_id_left", "mipt_bvh_id_right", "mipt_bvh_id_parent", "mipt_bvh_id_sibling",
@@ -135,6 +135,9 @@ def lib():
         getattr(L, n).argtypes = [C.c_char_p, C.c_int32, C.c_int32, fp]
     L.mipt_bvh_build.argtypes = [vp, C.POINTER(vp)]
     L.mipt_scene_cache_save.argtypes = [C.c_char_p, vp, vp]
+    L.mipt_image_pack_rgb8.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint8)]
+    L.mipt_image_compare.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t] + [C.POINTER(C.c_double)] * 3
+    L.mipt_pack_rgb8_device.argtypes = [vp, vp, C.c_size_t, vp]
     L.mipt_scene_cache_load.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(vp)]
     L.mipt_scene_exact_reciprocal.argtypes = [vp]
     L.mipt_scene_exact_reciprocal.restype = C.c_int32
@@ -339,6 +342,24 @@ def save_png(path, rgb):
     check(lib().mipt_image_save_png(os.fsencode(path), rgb.shape[1], rgb.shape[0], _fp(rgb)))
 
 
+def pack_rgb8(rgb):
+    """float image -> uint8 as Image::save converts it (no flip)"""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    out = np.empty(rgb.shape, np.uint8)
+    check(lib().mipt_image_pack_rgb8(_fp(rgb), rgb.size, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
+
+
+def compare_images(a, b):
+    """-> (rmse, mean_a, mean_b) over all channels, accumulated in double"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    assert a.shape == b.shape
+    r, ma, mb = C.c_double(), C.c_double(), C.c_double()
+    check(lib().mipt_image_compare(_fp(a), _fp(b), a.size, C.byref(r), C.byref(ma), C.byref(mb)))
+    return r.value, ma.value, mb.value
+
+
 def save_hdr(path, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)
     check(lib().mipt_image_save_hdr(os.fsencode(path), rgb.shape[1], rgb.shape[0], _fp(rgb)))
@@ -515,6 +536,10 @@ class Context:
     def buffer_free(self, ptr):
         check(lib().mipt_buffer_free(self.h, C.c_void_p(ptr)))
 
+    def buffer_upload(self, ptr, array):
+        a = np.ascontiguousarray(array)
+        check(lib().mipt_buffer_upload(self.h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
     def buffer_download(self, ptr, shape, dtype=np.float32):
         out = np.empty(shape, dtype)
         check(lib().mipt_buffer_download(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
@@ -522,6 +547,10 @@ class Context:
 
     def set_profiling(self, on):
         check(lib().mipt_context_set_profiling(self.h, int(on)))
+
+    def pack_rgb8_device(self, rgb_ptr, n_values, out_ptr):
+        """device float rgb -> device uint8, asynchronous on the context's stream (mipt_pack_rgb8_device)"""
+        check(lib().mipt_pack_rgb8_device(self.h, C.c_void_p(rgb_ptr), n_values, C.c_void_p(out_ptr)))
 
     def set_counting(self, on):
         check(lib().mipt_context_set_counting(self.h, int(on)))

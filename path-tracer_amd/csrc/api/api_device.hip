@@ -600,6 +600,15 @@ int mipt_buffer_zero(mipt_ctx* c, void* dev_ptr, size_t bytes) {
     if (bytes) HIP_TRY(hipMemsetAsync(dev_ptr, 0, bytes, c->stream));
     return MIPT_OK;
 }
+int mipt_pack_rgb8_device(mipt_ctx* c, const float* rgb_dev, size_t n_values, uint8_t* out_dev) {
+    if (!c || (n_values && (!rgb_dev || !out_dev))) return fail(MIPT_ERR_INVALID, "mipt_pack_rgb8_device: bad argument");
+    if (((uintptr_t)rgb_dev & 15u) || ((uintptr_t)out_dev & 3u))
+        return fail(MIPT_ERR_INVALID, "mipt_pack_rgb8_device: rgb_dev must be 16-byte aligned, out_dev 4-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n_values) ptd::launch_pack_rgb8(c->stream, rgb_dev, n_values, out_dev);
+    HIP_TRY(hipGetLastError());
+    return MIPT_OK;
+}
 int mipt_buffer_upload(mipt_ctx* c, void* dev_ptr, const void* host_ptr, size_t bytes) {
     if (!c || (bytes && (!dev_ptr || !host_ptr))) return fail(MIPT_ERR_INVALID, "mipt_buffer_upload: bad argument");
     HIP_TRY(hipSetDevice(c->device));

@@ -173,6 +173,16 @@ int mipt_image_save_pfm(const char* path, int32_t w, int32_t h, const float* rgb
     return pt::savePFM(path, w, h, rgb);
     MIPT_GUARD_END
 }
+int mipt_image_pack_rgb8(const float* rgb, size_t n_values, uint8_t* out) {
+    if (n_values && (!rgb || !out)) { pt::set_error("mipt_image_pack_rgb8: null argument"); return MIPT_ERR_INVALID; }
+    pt::packRGB8(rgb, n_values, out);
+    return MIPT_OK;
+}
+int mipt_image_compare(const float* a, const float* b, size_t n_values, double* rmse, double* mean_a, double* mean_b) {
+    if (n_values && (!a || !b)) { pt::set_error("mipt_image_compare: null argument"); return MIPT_ERR_INVALID; }
+    pt::compareImages(a, b, n_values, rmse, mean_a, mean_b);
+    return MIPT_OK;
+}
 void mipt_image_destroy(mipt_image* im) { delete im; }
 
 int mipt_bvh_build(const mipt_mesh* mesh, mipt_bvh** out) {

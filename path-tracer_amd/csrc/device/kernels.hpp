@@ -112,6 +112,8 @@ void launch_shade_b(hipStream_t st, const DevScene& s, const FrameParams& fp, co
 // that ended at a Lambertian vertex of bounce iter-1
 void launch_shade_path(hipStream_t st, const DevScene& s, const FrameParams& fp, const PathBuffers& pb, int iter, bool finalsOnly);
 // totals[0] += sum of extension-queue lengths, totals[1] += sum of shadow-queue lengths over iterations [0, nIter)
+// rgb (16-byte aligned) -> 8-bit channels as Image::save converts them; out 4-byte aligned
+void launch_pack_rgb8(hipStream_t st, const float* rgb, size_t nValues, unsigned char* out);
 void launch_resolve_samples(hipStream_t st, const FrameParams& fp, const PathBuffers& pb);
 void launch_fold_counters(hipStream_t st, const unsigned* counters, int nIter, unsigned long long* totals);
 

@@ -442,6 +442,25 @@ __global__ void k_fold_counters(const unsigned* __restrict__ counters, int nIter
     }
 }
 
+// ---- 8-bit frame: Image::save's per-channel conversion (C:159-168, C:228) on the device, four channels per lane ----
+// (unsigned char)(255.0f * gammaCorrection(toneMapping(v))) with gamma 1.0: pow(x, 1) is x, fmin/fmax are IEEE
+// minNum/maxNum on both sides, the conversion truncates; same bytes as pt::packChannel8 on the host.
+__device__ __forceinline__ unsigned pack_channel8(float r) {
+    const float tm = fmaxf(fminf(1.0f, r), 0.0f);
+    return (unsigned)(unsigned char)(255.0f * tm);
+}
+__global__ __launch_bounds__(kBlock) void k_pack_rgb8(const float* __restrict__ rgb, size_t nValues, unsigned char* __restrict__ out) {
+    const size_t nQuads = nValues >> 2;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nQuads; i += (size_t)gridDim.x * kBlock) {
+        const float4 v = ((const float4*)rgb)[i];
+        ((unsigned*)out)[i] = pack_channel8(v.x) | (pack_channel8(v.y) << 8) | (pack_channel8(v.z) << 16) | (pack_channel8(v.w) << 24);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (nValues & 3)) {
+        const size_t i = (nQuads << 2) + threadIdx.x;
+        out[i] = (unsigned char)pack_channel8(rgb[i]);
+    }
+}
+
 // ---- launchers ----
 static inline unsigned grid_for(size_t n) {
     size_t g = (n + kBlock - 1) / kBlock;
@@ -465,6 +484,9 @@ void launch_shade_path(hipStream_t st, const DevScene& s, const FrameParams& fp,
     hipLaunchKernelGGL(k_shade_path, dim3(grid_for(pb.space)), dim3(kBlock), 0, st, s, fp, pb, iter, finalsOnly ? 1 : 0);
 }
 
+void launch_pack_rgb8(hipStream_t st, const float* rgb, size_t nValues, unsigned char* out) {
+    hipLaunchKernelGGL(k_pack_rgb8, dim3(grid_for((nValues >> 2) + 1)), dim3(kBlock), 0, st, rgb, nValues, out);
+}
 void launch_resolve_samples(hipStream_t st, const FrameParams& fp, const PathBuffers& pb) {
     hipLaunchKernelGGL(k_resolve_samples, dim3(grid_for(fp.nTilePaths)), dim3(kBlock), 0, st, fp, pb);
 }

@@ -312,6 +312,28 @@ void putChunk(std::vector<uint8_t>& out, const char* type, const std::vector<uin
 
 }  // namespace
 
+// one channel of Image::save, C:228: (unsigned char)(255.0f * gammaCorrection(toneMapping(v)))
+uint8_t packChannel8(float r) {
+    const float tm = std::fmax(std::fmin(1.0f, r), 0.0f);  // toneMapping C:159-162; a NaN comes out as 1, as std::min(1.0f, NaN) does
+    const float g = powf(tm, 1.0f / 1.0f);                  // gammaCorrection C:164-168
+    return (unsigned char)(255.0f * g);
+}
+void packRGB8(const float* rgb, size_t nValues, uint8_t* out) {
+    for (size_t i = 0; i < nValues; i++) out[i] = packChannel8(rgb[i]);
+}
+// root-mean-square difference over all channels and the two means, in double
+void compareImages(const float* a, const float* b, size_t nValues, double* rmse, double* meanA, double* meanB) {
+    double se = 0.0, sa = 0.0, sb = 0.0;
+    for (size_t i = 0; i < nValues; i++) {
+        const double d = (double)a[i] - (double)b[i];
+        se += d * d; sa += a[i]; sb += b[i];
+    }
+    const double n = nValues ? (double)nValues : 1.0;
+    if (rmse) *rmse = std::sqrt(se / n);
+    if (meanA) *meanA = sa / n;
+    if (meanB) *meanB = sb / n;
+}
+
 int savePNG(const char* fileName, int width, int height, const float* rgb) {
     if (width <= 0 || height <= 0 || !rgb) {
         set_error("savePNG: bad arguments");
@@ -323,10 +345,7 @@ int savePNG(const char* fileName, int width, int height, const float* rgb) {
         raw.push_back(0);
         for (int i = 0; i < width; i++) {
             for (int c = 0; c < 3; c++) {
-                const float r = rgb[3 * ((size_t)j * width + i) + c];
-                const float tm = std::fmax(std::fmin(1.0f, r), 0.0f);  // toneMapping C:159-162 (NaN -> 0 like std::max/min order)
-                const float g = powf(tm, 1.0f / 1.0f);                  // gammaCorrection C:164-168
-                raw.push_back((unsigned char)(255.0f * g));
+                raw.push_back(packChannel8(rgb[3 * ((size_t)j * width + i) + c]));
             }
         }
     }

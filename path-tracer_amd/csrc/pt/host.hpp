@@ -64,6 +64,9 @@ public:
 int savePNG(const char* fileName, int width, int height, const float* rgb);  // Image::save C:223-236
 int saveHDR(const char* fileName, int width, int height, const float* rgb);
 int savePFM(const char* fileName, int width, int height, const float* rgb);
+uint8_t packChannel8(float v);                                        // one channel of Image::save, C:228
+void packRGB8(const float* rgb, size_t nValues, uint8_t* out);
+void compareImages(const float* a, const float* b, size_t nValues, double* rmse, double* meanA, double* meanB);
 // decoders shared by Image::load and the texture loader
 int decodePNG(const char* fileName, std::vector<uint8_t>& rgb, int& w, int& h);     // as stbi_load(..., 3)
 int decodeHDR(const char* fileName, std::vector<float>& rgb, int& w, int& h);       // as stbi_loadf(..., 3)

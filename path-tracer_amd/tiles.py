@@ -59,3 +59,25 @@ class TileGather:
             for r in range(1, self.world):
                 m = self.idx[r].numel()
                 rgb3.index_copy_(0, self.idx[r], self.recv[r][: m * 3].view(-1, 3))
+
+    def gather_rgb8(self, rgb8_flat):
+        """the same collective for a frame that has already been converted to 8 bits per channel on the device
+        (Context.pack_rgb8_device: Image::save's conversion): rgb8_flat is this rank's frame as a flat uint8 tensor
+        of width*height*3; rank 0 receives a quarter of the bytes of gather()"""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return
+        if not hasattr(self, "send8"):
+            dev = self.send.device
+            self.send8 = torch.zeros(self.max_own * 3, dtype=torch.uint8, device=dev)
+            self.recv8 = ([torch.zeros(self.max_own * 3, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+                          if self.rank == 0 else None)
+        rgb3 = rgb8_flat.view(-1, 3)
+        n = self.idx[self.rank].numel()
+        self.send8[: n * 3] = rgb3.index_select(0, self.idx[self.rank]).reshape(-1)
+        dist.gather(self.send8, self.recv8, dst=0)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                m = self.idx[r].numel()
+                rgb3.index_copy_(0, self.idx[r], self.recv8[r][: m * 3].view(-1, 3))

@@ -142,3 +142,25 @@ def test_primary_mode_and_errors(B, ob, sf):
         ctx.render(cam, mode=B.MODE_PATH, spp=1, tile_w=12)
     with pytest.raises(B.MiptError):
         ctx.render(B.default_camera(0, 10), mode=B.MODE_DIRECT)
+
+
+@pytest.mark.gpu
+def test_device_rgb8_pack_equals_host_conversion(B, sf):
+    """mipt_pack_rgb8_device writes the bytes Image::save would (host conversion, tests/test_host.py), for every
+    length mod 4 and for the special values"""
+    scene = sf.product_scene_from_mesh_arrays(*sf.load_scene_arrays("cornellbox"))
+    ctx = B.Context(scene, device=0)
+    rng = np.random.default_rng(4)
+    for n in (3 * 64 * 48, 1021, 2, 0):
+        v = rng.uniform(-0.5, 1.5, n).astype(np.float32)
+        if n > 16:
+            v[:9] = [0.0, -0.0, 1.0, 0.999999, 1.0 / 255, np.inf, -np.inf, np.nan, 1e-40]
+        src = ctx.buffer_alloc(4 * n + 16)
+        dst = ctx.buffer_alloc(n + 8)
+        ctx.buffer_upload(src, v)
+        ctx.buffer_upload(dst, np.full(n + 8, 7, np.uint8))
+        ctx.pack_rgb8_device(src, n, dst)
+        got = ctx.buffer_download(dst, (n + 8,), np.uint8)
+        ctx.buffer_free(src)
+        ctx.buffer_free(dst)
+        assert np.array_equal(got[:n], B.pack_rgb8(v)) and (got[n:] == 7).all()

@@ -296,3 +296,18 @@ def test_scene_cache_round_trip_and_rejects_damage(B, tmp_path):
             B.load_scene_cache(bad)
     with pytest.raises(B.MiptError):
         B.load_scene_cache(str(tmp_path / "missing.miptsc"))
+
+
+def test_pack_rgb8_and_compare_images(B):
+    """Image::save's channel conversion (C:159-168, C:228) and the RMSE helper, against numpy"""
+    rng = np.random.default_rng(2)
+    v = rng.uniform(-0.5, 1.5, 4099).astype(np.float32)
+    v[:8] = [0.0, -0.0, 1.0, 0.999999, 1.0 / 255, np.inf, -np.inf, 1e-40]
+    want = (np.float32(255.0) * np.clip(v, 0.0, 1.0).astype(np.float32)).astype(np.uint8)
+    assert np.array_equal(B.pack_rgb8(v), want)
+    assert B.pack_rgb8(np.array([np.nan], np.float32))[0] == 255  # std::min(1.0f, NaN) is 1.0f
+    a = rng.uniform(0, 4, (7, 5, 3)).astype(np.float32)
+    b = (a + rng.normal(0, 0.1, a.shape)).astype(np.float32)
+    rmse, ma, mb = B.compare_images(a, b)
+    assert abs(rmse - np.sqrt(np.mean((a.astype(np.float64) - b) ** 2))) < 1e-12
+    assert abs(ma - a.astype(np.float64).mean()) < 1e-12 and abs(mb - b.astype(np.float64).mean()) < 1e-12

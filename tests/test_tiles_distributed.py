@@ -40,6 +40,14 @@ def _worker(rank, world, port, width, height, out_path):
             others = torch.ones(n, dtype=torch.bool)
             others[mine] = False
             assert torch.count_nonzero(rgb.view(-1, 3)[others]) == 0  # non-root ranks receive nothing
+    # the 8-bit frame (after mipt_pack_rgb8_device) through the same collective, a quarter of the bytes
+    want8 = (torch.arange(n * 3, dtype=torch.int64) * 7 % 251).to(torch.uint8)
+    for step in range(2):
+        rgb8 = torch.zeros(n * 3, dtype=torch.uint8)
+        rgb8.view(-1, 3)[g.idx[rank]] = want8.view(-1, 3)[g.idx[rank]]
+        g.gather_rgb8(rgb8)
+        if rank == 0:
+            assert torch.equal(rgb8, want8), "assembled 8-bit frame differs"
     dist.barrier()
     if rank == 0:
         open(out_path, "w").write("ok")
