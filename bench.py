@@ -177,8 +177,11 @@ def main():
                          st["launches_occluded"])
         # the kernel behind the two traversal entries: the order-free 4-wide traversal when the scene qualifies
         # (each launch is followed by a literal-walk launch over the handful of rays it handed back), else the walk
-        wide = scene.wide_nodes > 0 and os.environ.get("MIPT_TRAVERSAL") != "walk"
-        names = ("k_trace_wide_closest", "k_trace_wide_occluded") if wide else ("k_trace_closest", "k_trace_occluded")
+        tv = os.environ.get("MIPT_TRAVERSAL")  # A/B runs: walk = literal threaded walk, bittrail = StacklessBVH2 literal
+        wide = scene.wide_nodes > 0 and tv not in ("walk", "bittrail")
+        names = (("k_trace_wide_closest", "k_trace_wide_occluded") if wide else
+                 ("k_trace_bittrail_closest", "k_trace_bittrail_occluded") if tv == "bittrail" else
+                 ("k_trace_closest", "k_trace_occluded"))
         dom, dom_name = (kc, names[0]) if st["ms_closest"] >= st["ms_occluded"] else (ko, names[1])
         traffic, valu_frac, l2_hit = None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)

@@ -302,6 +302,17 @@ int mipt_buffer_download(mipt_ctx* ctx, void* host_ptr, const void* dev_ptr, siz
  * `/`; this runs that sequence against `/` on n_pairs operand pairs on the GPU and reports the mismatches (0). */
 int mipt_selftest_fast_division(mipt_ctx* ctx, uint64_t n_pairs, uint32_t seed, uint64_t* mismatches);
 
+/* Which of the reference's traversals answers mipt_trace / mipt_occluded / the render loops of this context.
+ * All three return the same bits on every ray tested; they differ in the work they do.
+ *   DEFAULT   StacklessBVH::intersect / isHit (C:1661-1705) semantics through the order-free 4-wide traversal
+ *             (k_trace_wide), with the literal walk for the rays and scenes that do not qualify;
+ *   THREADED  the literal idHit / idMiss walk for every ray (k_trace) -- what MIPT_TRAVERSAL=walk selects;
+ *   BITTRAIL  StacklessBVH2::intersect (C:1732-1803), the traversal Scene instantiates (C:2008), literal
+ *             (k_trace_bittrail): near-first, culls on box.t < minHit.t, 32-bit trail; its box / triangle test
+ *             counts are the reference's.  MIPT_ERR_LIMIT for trees deeper than 31 levels (the trail's width). */
+enum { MIPT_TRAVERSAL_DEFAULT = 0, MIPT_TRAVERSAL_THREADED = 1, MIPT_TRAVERSAL_BITTRAIL = 2 };
+int mipt_context_set_traversal(mipt_ctx* ctx, int traversal);
+
 int mipt_context_synchronize(mipt_ctx* ctx);
 /* profiling: HIP events around every kernel launch on the context's stream */
 int mipt_context_set_profiling(mipt_ctx* ctx, int enabled);

@@ -82,10 +82,13 @@ SYMBOLS = [
     "mipt_trace", "mipt_trace_device", "mipt_occluded", "mipt_eye_rays", "mipt_background",
     "mipt_selftest_fast_division", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
     "mipt_render_device", "mipt_render", "mipt_context_synchronize", "mipt_context_set_profiling",
-    "mipt_context_set_counting", "mipt_context_get_stats", "mipt_context_reset_stats",
+    "mipt_context_set_counting", "mipt_context_get_stats", "mipt_context_reset_stats", "mipt_context_set_traversal",
 ]
 
 _lib = None
+
+
+TRAVERSAL_DEFAULT, TRAVERSAL_THREADED, TRAVERSAL_BITTRAIL = 0, 1, 2
 
 
 class MiptError(RuntimeError):
@@ -164,6 +167,7 @@ def lib():
     L.mipt_buffer_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.mipt_context_set_profiling.argtypes = [vp, C.c_int]
     L.mipt_context_set_counting.argtypes = [vp, C.c_int]
+    L.mipt_context_set_traversal.argtypes = [vp, C.c_int]
     L.mipt_context_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mipt_context_reset_stats.argtypes = [vp]
     _lib = L
@@ -551,6 +555,11 @@ class Context:
     def pack_rgb8_device(self, rgb_ptr, n_values, out_ptr):
         """device float rgb -> device uint8, asynchronous on the context's stream (mipt_pack_rgb8_device)"""
         check(lib().mipt_pack_rgb8_device(self.h, C.c_void_p(rgb_ptr), n_values, C.c_void_p(out_ptr)))
+
+    def set_traversal(self, traversal):
+        """TRAVERSAL_DEFAULT (order-free wide tree), TRAVERSAL_THREADED (literal idHit/idMiss walk) or
+        TRAVERSAL_BITTRAIL (StacklessBVH2::intersect, literal)"""
+        check(lib().mipt_context_set_traversal(self.h, int(traversal)))
 
     def set_counting(self, on):
         check(lib().mipt_context_set_counting(self.h, int(on)))

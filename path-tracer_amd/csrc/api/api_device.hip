@@ -49,6 +49,8 @@ struct mipt_scene {
     // 4-wide tree over the same leaves for the order-free traversal (device_scene.hpp "wide")
     std::vector<float4> wnodes, leafBox, leafHead;
     std::vector<int> nodeRight;
+    std::vector<int4> btLinks;  // StacklessBVH2 links in device numbering
+    bool btOk = false;
     int nWide = 0;
     bool wideOk = false;
 };
@@ -217,6 +219,7 @@ struct mipt_ctx {
     DevBuf sRays, sHits, sOut, sAux, sAux2;
     DevBuf slow;           // rays the wide kernel handed back (trace_closest / trace_occluded)
     bool useWide = true;   // MIPT_TRAVERSAL=walk in the environment forces the literal walk (A/B runs)
+    bool useBitTrail = false;  // mipt_context_set_traversal(MIPT_TRAVERSAL_BITTRAIL)
     // integrator state
     DevBuf pathMem, tileMem, frameMem;
     PathBuffers pb{};
@@ -288,7 +291,9 @@ void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView 
     Timer t(c, 0);
     count_launch(c, 0);
     unsigned long long* cnt = c->counting ? c->dTotals + 2 : nullptr;
-    if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
+    if (c->useBitTrail) {
+        launch_trace_bittrail_closest(c->stream, c->ds, rays, index, q, hits, cnt);
+    } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
         unsigned* sl = (unsigned*)c->slow.p;
         launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, sl, (int*)(sl + 2));
         launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, (const int*)(sl + 2), sl);  // short list: a wavefront per ray
@@ -305,7 +310,9 @@ void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueVie
     Timer t(c, 1);
     count_launch(c, 1);
     unsigned long long* cnt = c->counting ? c->dTotals + 4 : nullptr;
-    if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
+    if (c->useBitTrail) {
+        launch_trace_bittrail_occluded(c->stream, c->ds, rays, target, q, occ, cnt);
+    } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
         unsigned* sl = (unsigned*)c->slow.p;
         launch_trace_wide_occluded(c->stream, c->ds, rays, target, q, cursor, occ, cnt, sl, (int*)(sl + 2));
         launch_trace_slow_occluded(c->stream, c->ds, rays, target, occ, cnt, (const int*)(sl + 2), sl);
@@ -436,8 +443,20 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear(); s->nWide = 0; }
         if (s->wideOk) {  // build_wide has verified the binary tree: right child = where the left subtree's walk exits
             s->nodeRight.assign((size_t)n, 0);
-            for (int i = 0; i < n; i++)
-                if (d->leaf_count[i] == 0) s->nodeRight[(size_t)perm[i]] = perm[d->id_miss[d->id_hit[i]]];
+            s->btLinks.assign((size_t)n, make_int4(0, 0, 0, 0));  // root: idParent = idSibling = 0, C:1716-1717
+            std::vector<int> depthOf((size_t)n, 0);
+            int maxDepth = 0;
+            for (int i = 0; i < n; i++) {  // preorder: a parent comes before its children
+                if (d->leaf_count[i] != 0) continue;
+                const int l = d->id_hit[i], r = d->id_miss[l];
+                s->nodeRight[(size_t)perm[i]] = perm[r];
+                s->btLinks[(size_t)perm[i]].x = perm[r];
+                s->btLinks[(size_t)perm[l]].y = perm[i]; s->btLinks[(size_t)perm[l]].z = perm[r];  // C:1720-1723
+                s->btLinks[(size_t)perm[r]].y = perm[i]; s->btLinks[(size_t)perm[r]].z = perm[l];
+                depthOf[l] = depthOf[r] = depthOf[i] + 1;
+                if (depthOf[l] > maxDepth) maxDepth = depthOf[l];
+            }
+            s->btOk = maxDepth <= 31;  // the reference's 32-bit trail holds one bit per level
         }
         // textures -> one byte pool
         std::vector<int> texOfs((size_t)d->n_textures, 0);
@@ -499,7 +518,10 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     HIP_TRY(hipSetDevice(device));
     mipt_ctx* c = new mipt_ctx();
     c->device = device;
-    if (const char* tv = getenv("MIPT_TRAVERSAL")) c->useWide = std::string(tv) != "walk";
+    if (const char* tv = getenv("MIPT_TRAVERSAL")) {  // A/B runs without touching the caller: walk | bittrail
+        c->useWide = std::string(tv) != "walk";
+        c->useBitTrail = std::string(tv) == "bittrail" && s->btOk;
+    }
     if (stream) c->stream = (hipStream_t)stream;
     else {
         if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(MIPT_ERR_DEVICE, "hipStreamCreate failed"); }
@@ -517,7 +539,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t szLeafBox = align256(s->leafBox.size() * sizeof(float4) + 16);
     const size_t szLeafHead = align256(s->leafHead.size() * sizeof(float4) + 16);
     const size_t szRight = align256(s->nodeRight.size() * sizeof(int) + 16);
-    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights + szWide + szLeafBox + szLeafHead + szRight;
+    const size_t szBt = align256(s->btLinks.size() * sizeof(int4) + 16);
+    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights + szWide + szLeafBox + szLeafHead + szRight + szBt;
     std::vector<unsigned char> stage(total, 0);
     size_t o = 0;
     const size_t oNodes = o; memcpy(&stage[o], s->nodes.data(), s->nodes.size() * sizeof(float4)); o += szNodes;
@@ -530,7 +553,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t oWide = o; if (!s->wnodes.empty()) memcpy(&stage[o], s->wnodes.data(), s->wnodes.size() * sizeof(float4)); o += szWide;
     const size_t oLeafBox = o; if (!s->leafBox.empty()) memcpy(&stage[o], s->leafBox.data(), s->leafBox.size() * sizeof(float4)); o += szLeafBox;
     const size_t oLeafHead = o; if (!s->leafHead.empty()) memcpy(&stage[o], s->leafHead.data(), s->leafHead.size() * sizeof(float4)); o += szLeafHead;
-    const size_t oRight = o; if (!s->nodeRight.empty()) memcpy(&stage[o], s->nodeRight.data(), s->nodeRight.size() * sizeof(int));
+    const size_t oRight = o; if (!s->nodeRight.empty()) memcpy(&stage[o], s->nodeRight.data(), s->nodeRight.size() * sizeof(int)); o += szRight;
+    const size_t oBt = o; if (!s->btLinks.empty()) memcpy(&stage[o], s->btLinks.data(), s->btLinks.size() * sizeof(int4));
     if (hipMalloc(&c->arena, total) != hipSuccess) { mipt_context_destroy(c); return fail(MIPT_ERR_DEVICE, "hipMalloc(arena) failed"); }
     c->arenaBytes = total;
     if (hipMemcpy(c->arena, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
@@ -553,6 +577,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.leafBox = (const float4*)(base + oLeafBox);
     c->ds.leafHead = (const float4*)(base + oLeafHead);
     c->ds.nodeRight = (const int*)(base + oRight);
+    c->ds.btLinks = (const int4*)(base + oBt);
+    c->ds.btOk = s->btOk ? 1 : 0;
     c->ds.nWide = s->wideOk ? s->nWide : 0;
     c->ds.nWideTop = s->nWide < ptd::kWideTopNodes ? s->nWide : ptd::kWideTopNodes;
     if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||
@@ -656,6 +682,18 @@ static int drain_timers(mipt_ctx* c) {
     return MIPT_OK;
 }
 
+int mipt_context_set_traversal(mipt_ctx* c, int traversal) {
+    if (!c) return fail(MIPT_ERR_INVALID, "null context");
+    if (traversal == MIPT_TRAVERSAL_DEFAULT) { c->useBitTrail = false; c->useWide = true; return MIPT_OK; }
+    if (traversal == MIPT_TRAVERSAL_THREADED) { c->useBitTrail = false; c->useWide = false; return MIPT_OK; }
+    if (traversal == MIPT_TRAVERSAL_BITTRAIL) {
+        if (!c->ds.btOk)
+            return fail(MIPT_ERR_LIMIT, "bit-trail traversal needs a proper binary tree of depth <= 31 (the reference's 32-bit trail)");
+        c->useBitTrail = true;
+        return MIPT_OK;
+    }
+    return fail(MIPT_ERR_INVALID, "unknown traversal");
+}
 int mipt_context_get_stats(mipt_ctx* c, mipt_stats* out) {
     if (!c || !out) return fail(MIPT_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));

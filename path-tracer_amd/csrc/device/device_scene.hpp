@@ -23,6 +23,8 @@
 //             leaf triangle), 0} -- the leaf's exact box for the reference's exact predicate; read only for the
 //             few triangles that would change a ray's result, hence apart from leafHead
 //   nodeRight int per node: the right child of an interior node (device numbering), 0 for a leaf; k_trace_slow
+//   btLinks   int4 per node {idRight, idParent, idSibling, 0} (device numbering): the links of StacklessBVH2::build
+//             (cs488.h:1713-1730) for k_trace_bittrail; idLeft is the node's link
 //   leafTris  3 x float4 per triangle reference (48 B), in leaf (triList) order:
 //               {p0.xyz, bits(original triangle id)}
 //               {p0-p1,  bits(1 if last triangle of its leaf)}
@@ -57,6 +59,8 @@ struct DevScene {
     const float4* leafBox;
     const float4* leafHead;
     const int* nodeRight;   // right child of every interior node (device numbering; 0 for leaves), only when nWide > 0
+    const int4* btLinks;    // {idRight, idParent, idSibling, 0} per node (device numbering): StacklessBVH2's links, only when btOk
+    int btOk;               // the tree is a verified binary tree of depth <= 31: k_trace_bittrail may run
     int nWide, nWideTop;    // wide nodes [0, nWideTop) are kept in LDS by k_trace_wide
     int nTopNodes;   // nodes [0, nTopNodes) are the top of the tree, numbered first so that k_trace can hold them in LDS
     int planesTame;  // every box plane is 0 or has magnitude in [2^-61, 2^40] and min <= max: the exact reciprocal slab division may be used (traverse.hpp)

@@ -97,6 +97,11 @@ void launch_trace_slow_closest(hipStream_t st, const DevScene& s, const float4* 
                                unsigned long long* counters, const int* list, const unsigned* listCount);
 void launch_trace_slow_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, unsigned char* occ,
                                 unsigned long long* counters, const int* list, const unsigned* listCount);
+// StacklessBVH2::intersect, literal (kernels_trace_bittrail.hip); needs s.btOk
+void launch_trace_bittrail_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
+                                   float4* hits, unsigned long long* counters);
+void launch_trace_bittrail_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
+                                    unsigned char* occ, unsigned long long* counters);
 void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t count, float4* rays);
 void launch_resolve_hits(hipStream_t st, const DevScene& s, const float4* rays, const float4* hits, size_t n,
                          float* out);

@@ -254,3 +254,41 @@ def test_literal_walk_and_wide_traversal_agree(B, ob, sf, name, monkeypatch):
     walk_ctx.reset_stats(); walk_ctx.set_counting(True); walk_ctx.trace(o, d); b = walk_ctx.stats()
     assert b["tri_tests_closest"] <= a["tri_tests_closest"] <= 1.5 * b["tri_tests_closest"] + 16
     wide_ctx.set_counting(False); walk_ctx.set_counting(False)
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "bunny", "teapot-glass", "testObj", "sponza-standin-trace"])
+def test_bittrail_kernel_is_the_references_scene_traversal(B, ob, sf, name):
+    """SURVEY 8(a) row 9: StacklessBVH2::intersect (cs488.h:1732-1803), what Scene instantiates, as a literal GPU
+    kernel (mipt_context_set_traversal BITTRAIL).  Hits bit for bit against the oracle's bit-trail variant, AND the
+    same number of box tests and triangle tests (the traversal is ray-dependent: equal counts mean the same
+    culling decisions); the default traversal gives the same hits on the same rays; Scene::isHit through it"""
+    arrays = sf.sponza_standin(1) if name == "sponza-standin-trace" else sf.load_scene_arrays(name)
+    scene = sf.product_scene_from_mesh_arrays(*arrays)
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+    ctx = B.Context(scene, device=0)
+    cam = B.default_camera(200, 150)
+    o, d = ctx.eye_rays(cam)
+    rng = np.random.default_rng(9)
+    n2 = 20000  # incoherent rays from inside the scene's bounds
+    lo, hi = np.asarray(arrays[0], np.float32).reshape(-1, 3).min(0), np.asarray(arrays[0], np.float32).reshape(-1, 3).max(0)
+    o2 = (lo + (hi - lo) * rng.uniform(0.05, 0.95, (n2, 3))).astype(np.float32)
+    d2 = rng.normal(size=(n2, 3)).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True).astype(np.float32)
+    o = np.concatenate([o, o2]); d = np.concatenate([d, d2])
+    default_hits = ctx.trace(o, d)
+    ctx.set_traversal(B.TRAVERSAL_BITTRAIL)
+    ctx.reset_stats()
+    ctx.set_counting(True)
+    a = ctx.trace(o, d)
+    st = ctx.stats()
+    ctx.set_counting(False)
+    b = orc.intersect(o, d, variant=ob.BITTRAIL)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[2]), bits(b[2]))
+    assert (st["node_visits_closest"], st["tri_tests_closest"]) == orc.last_counts
+    assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(a, default_hits))
+    far = float(np.linalg.norm(hi - lo)) * 0.25
+    assert np.array_equal(ctx.occluded(o, d, 0.0, far), orc.occluded(o, d, 0.0, far, variant=ob.BITTRAIL))
+    ctx.set_traversal(B.TRAVERSAL_THREADED)
+    c = ctx.trace(o, d)
+    assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(c, default_hits))
+    ctx.set_traversal(B.TRAVERSAL_DEFAULT)

@@ -16,7 +16,7 @@ if [ "$1" = build ]; then
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src/device/kernels_trace.hip -o $out/kt_$name.o
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src/device/kernels_trace_wide.hip -o $out/kw_$name.o
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src/api/api_device.hip -o $out/api_$name.o   # kTopNodes / kWideTopNodes are used on the host side too
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libmipt_$name.so $out/kt_$name.o $out/kw_$name.o $src/device/kernels_integrate.o \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libmipt_$name.so $out/kt_$name.o $out/kw_$name.o $src/device/kernels_integrate.o $src/device/kernels_trace_bittrail.o \
         $out/api_$name.o $src/api/api_host.o $src/host/obj_loader.o $src/host/bvh_build.o $src/host/image_io.o $src/host/scene_cache.o -lz
     rm -f $out/kt_$name.o $out/kw_$name.o $out/api_$name.o
     echo "built $name ($defs)"
