@@ -6,6 +6,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 #include <queue>
 #include <string>
@@ -132,6 +133,10 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
                 else { sl[ns++] = left[c]; sl[ns++] = right[c]; }
             }
         }
+        if (const char* so = getenv("MIPT_WIDE_SLOT_ORDER")) {  // experiment: static slot order (any-hit rays take the lowest hit slot first)
+            const int dir = !strcmp(so, "big") ? 1 : !strcmp(so, "small") ? -1 : 0;
+            if (dir) std::stable_sort(sl, sl + ns, [&](int a, int b) { return dir > 0 ? boxArea(a) > boxArea(b) : boxArea(a) < boxArea(b); });
+        }
         if (slotsOf.size() < 4 * wide.size()) slotsOf.resize(4 * wide.size(), -1);
         wide[w].childBase = (int)wide.size();
         for (int k = 0; k < 4; k++) {
@@ -146,7 +151,7 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
     }
     const int nw = (int)wide.size();
     slotsOf.resize((size_t)4 * nw, -1);
-    s->wnodes.assign((size_t)ptd::kWideNodeF4 * nw, make_float4(0, 0, 0, 0));
+    s->wnodes.assign((size_t)ptd::kWideNodeStrideF4 * nw, make_float4(0, 0, 0, 0));
     // second pass: records (children of wide node w start at its childBase, in the order the first pass appended them)
     int nextChild = 1;
     for (int w = 0; w < nw; w++) {
@@ -165,13 +170,14 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
                                                  __builtin_bit_cast(float, d->leaf_first[b]), 0.0f));
                 for (int r = 0; r < 3; r++) s->leafHead.push_back(s->leafTris[(size_t)3 * d->leaf_first[b] + r]);  // its first triangle
                 s->leafHead.back().w = __builtin_bit_cast(float, d->leaf_first[b]);  // ... tagged with its leafTris index
+                for (int r = 3; r < ptd::kLeafHeadStrideF4; r++) s->leafHead.push_back(make_float4(0, 0, 0, 0));  // padding to the record stride
                 nLeaves++;
             } else {
                 interiorMask |= 1 << k;
                 nextChild++;
             }
         }
-        float4* rec = &s->wnodes[(size_t)ptd::kWideNodeF4 * w];
+        float4* rec = &s->wnodes[(size_t)ptd::kWideNodeStrideF4 * w];
         for (int a = 0; a < 3; a++) {
             rec[2 * a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
             rec[2 * a + 1] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);

@@ -80,7 +80,15 @@ constexpr int kTraceBlock = PT_TUNE_BLOCK;  // k_trace: 16 wavefronts per block,
 #ifndef PT_TUNE_GRID
 #define PT_TUNE_GRID 512
 #endif
-constexpr int kWideNodeF4 = 7;      // float4 per wide node
+constexpr int kWideNodeF4 = 7;      // float4 per wide node (its stride in LDS)
+#ifndef PT_TUNE_WIDE_NODE_STRIDE
+#define PT_TUNE_WIDE_NODE_STRIDE 7
+#endif
+#ifndef PT_TUNE_LEAFHEAD_STRIDE
+#define PT_TUNE_LEAFHEAD_STRIDE 3
+#endif
+constexpr int kWideNodeStrideF4 = PT_TUNE_WIDE_NODE_STRIDE;  // ... and in the arena (8 = one 128-B line per node)
+constexpr int kLeafHeadStrideF4 = PT_TUNE_LEAFHEAD_STRIDE;   // float4 per leafHead record (4 = half a line each)
 constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's per-lane stack can hold (binary depth 32)
 #ifndef PT_TUNE_WIDE_BLOCK
 #define PT_TUNE_WIDE_BLOCK 1024

@@ -135,6 +135,14 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
 #endif
     // wavefront-uniform chunk of ray indices
     unsigned chunkBase = 0, chunkLeft = 0, chunkShard = 0;
+    // Rays are handed out in chunks, one atomic on the launch's one cursor per chunk.  Atomics on one address
+    // complete about one per 12 ns on this chip: at 64 rays per atomic that alone caps a launch at 5.5 G rays/s
+    // (measured with rays that miss the root box: 3.0 ms per 16.8 M rays, whatever the kernel did per ray), which
+    // is where both traversal kernels stood.  Guided self-scheduling: a wavefront asks for half of its share of
+    // what was left when it last looked (64..1024 rays), so chunks are large while the queue is long and shrink
+    // to 64 at the end, where they decide how evenly the wavefronts finish.
+    const unsigned nWaves = gridDim.x * (unsigned)(kTraceBlock / 64);
+    unsigned lastBase = 0;
     bool exhausted = (total == 0);
     constexpr int kDepth = ANYHIT ? kPendAnyHit : kPendClosest;  // leaves a lane may park (1..4)
     // triangle steps start when this many lanes hold parked leaves and go on while kLeafLanesKeep still do
@@ -165,13 +173,16 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
             // ---- refill: empty lanes take the next rays of the queue ----
             if (chunkLeft == 0) {
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(cursor, 64u);
+                unsigned chunkRays = ((total - lastBase) / (nWaves * 2u)) & ~63u;
+                chunkRays = chunkRays < 64u ? 64u : (chunkRays > 1024u ? 1024u : chunkRays);
+                if (lane == 0) base = atomicAdd(cursor, chunkRays);
                 base = __shfl(base, 0);
                 if (base >= total) {
                     exhausted = true;
                 } else {
                     chunkBase = base;
-                    chunkLeft = (total - base) < 64u ? (total - base) : 64u;
+                    lastBase = base;
+                    chunkLeft = (total - base) < chunkRays ? (total - base) : chunkRays;
                     // shard of the chunk's first ray: the number of shards that end at or before it (one vote
                     // instead of a binary search per lane; lanes step on from here, usually zero times)
                     if (q.counts && !remap) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= base));

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     __shared__ unsigned prefix[kShards + 1];
     const int lane = threadIdx.x & 63;
     const int nTop = s.nWideTop;
-    for (int i = threadIdx.x; i < kWideNodeF4 * nTop; i += kWideBlock) top[i] = s.wnodes[i];
+    for (int i = threadIdx.x; i < kWideNodeF4 * nTop; i += kWideBlock)  // packed in LDS, kWideNodeStrideF4 apart in the arena
+        top[i] = s.wnodes[(i / kWideNodeF4) * kWideNodeStrideF4 + i % kWideNodeF4];
     if (q.counts) {
         if (threadIdx.x < 64) {
             unsigned v = q.counts[(size_t)lane * kCntStride];
@@ -156,6 +157,14 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     float bestT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;
     unsigned nv = 0, nt = 0;
     unsigned chunkBase = 0, chunkLeft = 0, chunkShard = 0;
+    // Rays are handed out in chunks, one atomic on the launch's one cursor per chunk.  Atomics on one address
+    // complete about one per 12 ns on this chip: at 64 rays per atomic that alone caps a launch at 5.5 G rays/s
+    // (measured with rays that miss the root box: 3.0 ms per 16.8 M rays, whatever the kernel did per ray), which
+    // is where both traversal kernels stood.  Guided self-scheduling: a wavefront asks for half of its share of
+    // what was left when it last looked (64..1024 rays), so chunks are large while the queue is long and shrink
+    // to 64 at the end, where they decide how evenly the wavefronts finish.
+    const unsigned nWaves = gridDim.x * (unsigned)(kWideBlock / 64);
+    unsigned lastBase = 0;
     bool exhausted = (total == 0);
 
 #define PT_FINISH()                                                                        \
@@ -181,13 +190,16 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
             // ---- refill: empty lanes take the next rays of the queue ----
             if (chunkLeft == 0) {
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(cursor, 64u);
+                unsigned chunkRays = ((total - lastBase) / (nWaves * 2u)) & ~63u;
+                chunkRays = chunkRays < 64u ? 64u : (chunkRays > 1024u ? 1024u : chunkRays);
+                if (lane == 0) base = atomicAdd(cursor, chunkRays);
                 base = __shfl(base, 0);
                 if (base >= total) {
                     exhausted = true;
                 } else {
                     chunkBase = base;
-                    chunkLeft = (total - base) < 64u ? (total - base) : 64u;
+                    lastBase = base;
+                    chunkLeft = (total - base) < chunkRays ? (total - base) : chunkRays;
                     if (q.counts) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= base));
                 }
             }
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     nearx = topLds[a + sx]; farx = topLds[a + (sx ^ 1)]; neary = topLds[a + 2 + sy]; fary = topLds[a + 2 + (sy ^ 1)];
                     nearz = topLds[a + 4 + sz]; farz = topLds[a + 4 + (sz ^ 1)]; meta = topLds[a + 6];
                 } else {
-                    const size_t a = (size_t)kWideNodeF4 * (size_t)w;
+                    const size_t a = (size_t)kWideNodeStrideF4 * (size_t)w;
                     nearx = nodesGlobal[a + sx]; farx = nodesGlobal[a + (sx ^ 1)]; neary = nodesGlobal[a + 2 + sy];
                     fary = nodesGlobal[a + 2 + (sy ^ 1)]; nearz = nodesGlobal[a + 4 + sz]; farz = nodesGlobal[a + 4 + (sz ^ 1)];
                     meta = nodesGlobal[a + 6];
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     const __attribute__((address_space(1))) float4v* triAt;
                     if (opening) {
                         curLeaf = group_take(g0);
-                        triAt = (const __attribute__((address_space(1))) float4v*)s.leafHead + 3 * (size_t)curLeaf;
+                        triAt = (const __attribute__((address_space(1))) float4v*)s.leafHead + kLeafHeadStrideF4 * (size_t)curLeaf;
                         if ((g0 & 15u) == 0u) {
                             g0 = g1; g1 = g2; g2 = g3;
                             --groups;
