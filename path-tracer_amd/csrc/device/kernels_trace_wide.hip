@@ -35,7 +35,7 @@ namespace ptd {
 #define PT_TUNE_WIDE_WAVES 4
 #endif
 #ifndef PT_TUNE_WIDE_BURST
-#define PT_TUNE_WIDE_BURST 4
+#define PT_TUNE_WIDE_BURST 8          // visits between two votes, closest hit (4: 5.96 ms per bench launch, 6: 5.85, 8: 5.81)
 #endif
 #ifndef PT_TUNE_WIDE_REFILL
 #define PT_TUNE_WIDE_REFILL 16
@@ -48,6 +48,9 @@ namespace ptd {
 #endif
 #ifndef PT_TUNE_WIDE_STUCK
 #define PT_TUNE_WIDE_STUCK 8
+#endif
+#ifndef PT_TUNE_WIDE_BURST_ANYHIT
+#define PT_TUNE_WIDE_BURST_ANYHIT 4   // ... any hit: rays end early, shorter bursts waste fewer visits (3: 1.70 ms, 4: 1.62, 6: 1.67)
 #endif
 #ifndef PT_TUNE_WIDE_LEAF_ANYHIT
 #define PT_TUNE_WIDE_LEAF_ANYHIT PT_TUNE_WIDE_LEAF
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         }
         // ---- visits: lanes with a node to visit and room for one more leaf group ----
 #pragma unroll
-        for (int b = 0; b < PT_TUNE_WIDE_BURST; b++) {
+        for (int b = 0; b < (ANYHIT ? PT_TUNE_WIDE_BURST_ANYHIT : PT_TUNE_WIDE_BURST); b++) {
 #if PT_DIAG_UTIL == 1
             if (COUNT) { const unsigned long long ma = __ballot(w >= 0 && groups < kWideGroups); if (ma) { nv += (w >= 0 && groups < kWideGroups) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; } }
 #endif
