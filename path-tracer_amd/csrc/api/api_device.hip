@@ -493,7 +493,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
             s->materials[(size_t)4 * i + 2] = make_float4(m.Ks[0], m.Ks[1], m.Ks[2], __builtin_bit_cast(float, th));
             s->materials[(size_t)4 * i + 3] = make_float4(m.Ka[0], m.Ka[1], m.Ka[2], 0.0f);
         }
-        s->triAttr.resize((size_t)7 * d->n_tris);
+        s->triAttr.assign((size_t)ptd::kTriAttrF4 * d->n_tris, make_float4(0, 0, 0, 0));
         for (int t = 0; t < d->n_tris; t++) {
             if (d->mat_id[t] < 0 || d->mat_id[t] >= d->n_materials) { delete s; return fail(MIPT_ERR_INVALID, "mat_id out of range"); }
             float f[28];
@@ -503,7 +503,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
             const int mid = d->mat_id[t];
             memcpy(f + 24, &mid, 4);
             f[25] = f[26] = f[27] = 0.0f;
-            memcpy(&s->triAttr[(size_t)7 * t], f, sizeof f);
+            memcpy(&s->triAttr[(size_t)ptd::kTriAttrF4 * t], f, sizeof f);
         }
         if (d->env_width > 0) s->env.assign(d->env_rgb, d->env_rgb + (size_t)3 * d->env_width * d->env_height);
         s->lights.resize((size_t)2 * d->n_lights);

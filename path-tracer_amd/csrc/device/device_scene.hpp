@@ -32,7 +32,7 @@
 //             the two edge vectors are the first two operands of the
 //             reference's Cramer test (cs488.h:782-783), rounded once on the
 //             host exactly as the reference rounds them per test
-//   triAttr   7 x float4 per triangle (112 B), original order, for shading only:
+//   triAttr   8 x float4 per triangle (128 B = one cache line per shaded hit; 7 used), original order, for shading only:
 //               p0 p1 p2 n0 n1 n2 (18 floats) uv0 uv1 uv2 (6) bits(material id) pad
 //   materials 4 x float4 per material: {type, eta, Ns, bits(texel offset or -1)}
 //               {Kd.xyz, bits(texW)} {Ks.xyz, bits(texH)} {Ka.xyz, 0}
@@ -80,6 +80,7 @@ constexpr int kTraceBlock = PT_TUNE_BLOCK;  // k_trace: 16 wavefronts per block,
 #ifndef PT_TUNE_GRID
 #define PT_TUNE_GRID 512
 #endif
+constexpr int kTriAttrF4 = 8;       // float4 per triAttr record
 constexpr int kWideNodeF4 = 7;      // float4 per wide node (its stride in LDS)
 #ifndef PT_TUNE_WIDE_NODE_STRIDE
 #define PT_TUNE_WIDE_NODE_STRIDE 7

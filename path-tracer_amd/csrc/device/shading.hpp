@@ -30,7 +30,7 @@ struct HitInfo {  // C:510-517
 // second half of raytraceTriangle, C:800-809
 __device__ __forceinline__ HitInfo reconstruct_hit(const DevScene& s, int tri, float t, float beta, float gamma,
                                                    const vec3 rayD) {
-    const float4* a = s.triAttr + (size_t)7 * tri;
+    const float4* a = s.triAttr + (size_t)kTriAttrF4 * tri;
     const float4 q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3], q4 = a[4], q5 = a[5], q6 = a[6];
     const vec3 p0{q0.x, q0.y, q0.z}, p1{q0.w, q1.x, q1.y}, p2{q1.z, q1.w, q2.x};
     const vec3 n0{q2.y, q2.z, q2.w}, n1{q3.x, q3.y, q3.z}, n2{q3.w, q4.x, q4.y};
