@@ -263,16 +263,24 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
 #endif
             if (w >= 0 && groups < kWideGroups) {
                 float4v nearx, farx, neary, fary, nearz, farz, meta;  // rows picked by the direction signs (sx, sy, sz)
+                // byte offsets of the seven rows inside the record, the same for both homes of a node; 32-bit
+                // offsets from a uniform base let the loads address with base + offset instead of 64-bit sums
+                const unsigned rxn = (unsigned)sx << 4, rxf = 16u - rxn, ryn = 32u + ((unsigned)sy << 4), ryf = 80u - ryn,
+                               rzn = 64u + ((unsigned)sz << 4), rzf = 144u - rzn;
+#define PT_ROW(AS, BASE, OFS) (*(const __attribute__((address_space(AS))) float4v*)((const __attribute__((address_space(AS))) char*)(BASE) + (OFS)))
                 if (w < nTop) {  // top of the tree: from LDS
-                    const int a = kWideNodeF4 * w;
-                    nearx = topLds[a + sx]; farx = topLds[a + (sx ^ 1)]; neary = topLds[a + 2 + sy]; fary = topLds[a + 2 + (sy ^ 1)];
-                    nearz = topLds[a + 4 + sz]; farz = topLds[a + 4 + (sz ^ 1)]; meta = topLds[a + 6];
+                    const unsigned a = __umul24((unsigned)w, 16u * kWideNodeF4);
+                    nearx = PT_ROW(3, topLds, a + rxn); farx = PT_ROW(3, topLds, a + rxf); neary = PT_ROW(3, topLds, a + ryn);
+                    fary = PT_ROW(3, topLds, a + ryf); nearz = PT_ROW(3, topLds, a + rzn); farz = PT_ROW(3, topLds, a + rzf);
+                    meta = PT_ROW(3, topLds, a + 96u);
                 } else {
-                    const size_t a = (size_t)kWideNodeStrideF4 * (size_t)w;
-                    nearx = nodesGlobal[a + sx]; farx = nodesGlobal[a + (sx ^ 1)]; neary = nodesGlobal[a + 2 + sy];
-                    fary = nodesGlobal[a + 2 + (sy ^ 1)]; nearz = nodesGlobal[a + 4 + sz]; farz = nodesGlobal[a + 4 + (sz ^ 1)];
-                    meta = nodesGlobal[a + 6];
+                    const unsigned a = __umul24((unsigned)w, 16u * kWideNodeStrideF4);  // < 2^22 nodes x 128 B
+                    nearx = PT_ROW(1, nodesGlobal, (size_t)(a + rxn)); farx = PT_ROW(1, nodesGlobal, (size_t)(a + rxf));
+                    neary = PT_ROW(1, nodesGlobal, (size_t)(a + ryn)); fary = PT_ROW(1, nodesGlobal, (size_t)(a + ryf));
+                    nearz = PT_ROW(1, nodesGlobal, (size_t)(a + rzn)); farz = PT_ROW(1, nodesGlobal, (size_t)(a + rzf));
+                    meta = PT_ROW(1, nodesGlobal, (size_t)(a + 96u));
                 }
+#undef PT_ROW
                 const int masks = f2i(meta.z);
                 const int imask = masks & 15, lmask = (masks >> 4) & 15;
 #if !PT_DIAG_UTIL
