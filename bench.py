@@ -72,7 +72,52 @@ def cpu_baseline(arrays, env, lights, eye, lookat):
                       f"{rays} rays in {dt:.1f} s, bit-trail traversal, 1 thread"}
 
 
+def _cpu_worker(job):
+    """one process of the all-cores leg: rows start, start + stride, ... of the same frame for about `budget` seconds"""
+    detail, start, stride, budget = job
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_binding as ob
+    import scene_fixtures as sf
+    orc = sf.oracle_scene_from_mesh_arrays(*sf.sponza_standin(detail), env=sf.procedural_env(1024), lights=sf.SPONZA_LIGHT)
+    cam = ob.make_camera(W, H, eye=sf.SPONZA_EYE, lookat=sf.SPONZA_LOOKAT)
+    rays, rows, t0 = 0, 0, time.perf_counter()
+    for r in range(start, H, stride):
+        orc.pathtrace(cam, spp=1, max_bounces=BOUNCES, rng_mode=1, seed=SEED, variant=ob.BITTRAIL, rows=(r, r + 1))
+        rays += orc.last_rays
+        rows += 1
+        if time.perf_counter() - t0 > budget:
+            break
+    return rays, rows, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(detail, budget=10.0):
+    """the same oracle, scanline-parallel over the host cores this job may use (the counter RNG makes
+    rows independent).  Child processes of this script (`--cpu-rows`), none of which touches the GPU; each is
+    waited for with a time limit and killed by its own pid if it overstays"""
+    import subprocess
+    cores = max(1, min(16, os.cpu_count() or 1))  # the GPU box gives a one-GPU job 16 CPUs
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-rows", str(detail), str(k), str(cores), str(budget)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(cores)]
+    res = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=budget + 90.0)
+            res.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            pr.kill()
+            pr.wait()
+    if not res:
+        raise RuntimeError("no CPU worker finished")
+    rays = sum(r[0] for r in res)
+    dt = max(r[2] for r in res)
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": len(res),
+            "sample": f"{sum(r[1] for r in res)} rows interleaved over {len(res)} processes, {rays} rays in {dt:.1f} s"}
+
+
 def main():
+    if len(sys.argv) == 6 and sys.argv[1] == "--cpu-rows":  # a worker of cpu_baseline_all_cores: no torch, no GPU
+        print(json.dumps(_cpu_worker((int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])))), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -239,6 +284,10 @@ def main():
                 out["config"]["primary_only_error"] = str(e)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(arrays, env, sf.SPONZA_LIGHT, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
+            try:  # the same oracle on all the cores of this job, reported beside the 1-thread figure
+                out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(args.detail)
+            except Exception as e:
+                out["cpu_baseline"]["all_cores"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
