@@ -81,12 +81,14 @@ def _cpu_worker(job):
     orc = sf.oracle_scene_from_mesh_arrays(*sf.sponza_standin(detail), env=sf.procedural_env(1024), lights=sf.SPONZA_LIGHT)
     cam = ob.make_camera(W, H, eye=sf.SPONZA_EYE, lookat=sf.SPONZA_LOOKAT)
     rays, rows, t0 = 0, 0, time.perf_counter()
-    for r in range(start, H, stride):
-        orc.pathtrace(cam, spp=1, max_bounces=BOUNCES, rng_mode=1, seed=SEED, variant=ob.BITTRAIL, rows=(r, r + 1))
-        rays += orc.last_rays
-        rows += 1
-        if time.perf_counter() - t0 > budget:
-            break
+    for sample in range(64):  # its rows of sample 0 of the frame, then of sample 1, ... until the budget is spent
+        for r in range(start, H, stride):
+            orc.pathtrace(cam, spp=1, sample_offset=sample, max_bounces=BOUNCES, rng_mode=1, seed=SEED, variant=ob.BITTRAIL,
+                          rows=(r, r + 1))
+            rays += orc.last_rays
+            rows += 1
+            if time.perf_counter() - t0 > budget:
+                return rays, rows, time.perf_counter() - t0
     return rays, rows, time.perf_counter() - t0
 
 
