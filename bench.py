@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--with-primary", action="store_true",
                     help="also time configs[0] (cornellbox 512x512 primary rays only); off by default so that the kernel "
                          "averages of a rocprofv3 run of this command are those of the headline workload")
+    ap.add_argument("--spp", type=int, default=SPP, help="samples per GPU per step (default 16 = BASELINE configs[3]; other "
+                                                         "values are for studying launch-size effects, not the headline)")
     ap.add_argument("--detail", type=int, default=1, help="sponza-standin tessellation (1: 65,536 tris, 2: 256,768)")
     args = ap.parse_args()
 
@@ -161,7 +163,7 @@ def main():
 
     gatherer = pkg.tiles.TileGather(W, H, rank, world, dev, TILE_W, TILE_H)  # owned pixels -> rank 0, one RCCL gather per step
 
-    spp_per_step = SPP * world  # one 16-spp frame-equivalent of paths per GPU per step
+    spp_per_step = args.spp * world  # one 16-spp frame-equivalent of paths per GPU per step
     state = {"sample": 0}
 
     def step():
@@ -244,11 +246,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"sponza-standin ({len(arrays[3])} tris, procedural; sponza.obj absent) 1920x1080 "
-                                   f"path trace, {BOUNCES} bounces, {SPP} spp per GPU per step, procedural env "
+                                   f"path trace, {BOUNCES} bounces, {args.spp} spp per GPU per step, procedural env "
                                    f"(uffizi_probe.hdr absent), tiles {TILE_W}x{TILE_H} interleaved over {world} GPU(s), "
                                    f"RCCL gather to rank 0" if world > 1 else
                                    f"sponza-standin ({len(arrays[3])} tris, procedural; sponza.obj absent) 1920x1080 "
-                                   f"path trace, {BOUNCES} bounces, {SPP} spp per step, procedural env (uffizi_probe.hdr absent)",
+                                   f"path trace, {BOUNCES} bounces, {args.spp} spp per step, procedural env (uffizi_probe.hdr absent)",
                        "resolution": [W, H], "bounces": BOUNCES, "spp_per_step": spp_per_step, "seed": SEED,
                        "rays_per_step": total_rays / args.steps,
                        "ms_per_frame_1spp": elapsed_max / args.steps * 1e3 / spp_per_step * world},
