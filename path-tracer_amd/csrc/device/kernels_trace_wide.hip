@@ -49,6 +49,9 @@ namespace ptd {
 #ifndef PT_TUNE_WIDE_STUCK
 #define PT_TUNE_WIDE_STUCK 8
 #endif
+#ifndef PT_TUNE_WIDE_REFILL_ANYHIT
+#define PT_TUNE_WIDE_REFILL_ANYHIT PT_TUNE_WIDE_REFILL
+#endif
 #ifndef PT_TUNE_WIDE_BURST_ANYHIT
 #define PT_TUNE_WIDE_BURST_ANYHIT 4   // ... any hit: rays end early, shorter bursts waste fewer visits (3: 1.70 ms, 4: 1.62, 6: 1.67)
 #endif
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         const unsigned long long mEmpty = __ballot(!hasRay);
         const int nEmpty = __popcll(mEmpty);
         if (nEmpty == 64 && exhausted) break;
-        if (!exhausted && nEmpty >= PT_TUNE_WIDE_REFILL) {
+        if (!exhausted && nEmpty >= (ANYHIT ? PT_TUNE_WIDE_REFILL_ANYHIT : PT_TUNE_WIDE_REFILL)) {
             // ---- refill: empty lanes take the next rays of the queue ----
             if (chunkLeft == 0) {
                 unsigned base = 0;
