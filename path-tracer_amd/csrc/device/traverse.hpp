@@ -131,7 +131,11 @@ __device__ __forceinline__ bool tri_test(const vec3 p0, const vec3 a, const vec3
     const float alpha = 1.0f - beta - gamma;
     if (alpha > 1.0f || alpha < 0.0f || beta < 0.0f || gamma < 0.0f) return false;
     t = C / D;
-    return t > tMin && t < tMax && (double)t > 0.00001;
+    // `t > 0.00001` in the reference compares (double)t with the double 1e-5 (cs488.h:812).  (float)1e-5 =
+    // 9.99999974738e-06 lies BELOW 1e-5 and the next float, 1.00000006569e-05, above it, so for every float t
+    // (double)t > 1e-5  <=>  t > (float)1e-5: the same predicate without the two fp64 instructions.
+    static_assert((double)0.00001f < 0.00001, "the float nearest to 1e-5 must lie below it");
+    return t > tMin && t < tMax && t > 0.00001f;
 }
 
 }  // namespace ptd
