@@ -17,12 +17,14 @@
 // isHit (cs488.h:1684-1705) returns "some accepted triangle exists", which is order-free by itself.
 //
 // This kernel does that for the rays that qualify (fast_div_ok, in a scene whose planes are tame and whose tree
-// build_wide() accepted): a 4-wide tree (one node = a binary node's grandchildren), all four boxes of a node
-// tested in straight-line code with a cheap conservative test (a * RN(1/d) instead of the exact division, widened
-// by 2^-20), a per-lane stack of one packed entry per level, leaves parked and opened later with the exact test.
-// One visit replaces four steps of the threaded walk (the walk spends as many issue slots on its exec-mask
-// juggling per box as on arithmetic: DESIGN.md).  Rays that do not qualify are appended to a list; the host runs
-// the literal walk (k_trace in kernels_trace.hip) over that list afterwards.
+// build_wide() accepted): a 4-wide tree (a node's slots = a binary node's children opened largest box first until
+// four are taken), all four boxes of a node tested in straight-line code with a cheap conservative test (plane
+// offset times a reciprocal that carries the slack, instead of the exact division), a per-lane stack of one packed
+// entry per visited node with hit children, leaves parked and tested later: triangle first, the exact box
+// predicate only for a triangle that would change the result.  One visit replaces about four steps of the threaded
+// walk (the walk spends as many issue slots on its exec-mask juggling per box as on arithmetic: DESIGN.md).  Rays
+// that do not qualify are appended to a list; NaN rays are answered as misses at once; after the launch the list
+// is traced by k_trace_slow (a wavefront per ray) or, when it is long, by the literal k_trace (kernels_trace.hip).
 #include "kernels.hpp"
 #include "shading.hpp"
 
