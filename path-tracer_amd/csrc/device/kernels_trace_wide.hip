@@ -67,7 +67,10 @@ namespace ptd {
 #define PT_TUNE_WIDE_STUCK_ANYHIT PT_TUNE_WIDE_STUCK
 #endif
 constexpr int kWideBlock = PT_TUNE_WIDE_BLOCK;
-constexpr int kWideGroups = 4;  // leaf groups a lane may hold (one group = the leaf slots of one wide node)
+#ifndef PT_TUNE_WIDE_GROUPS
+#define PT_TUNE_WIDE_GROUPS 4
+#endif
+constexpr int kWideGroups = PT_TUNE_WIDE_GROUPS;  // leaf groups a lane may hold (one group = the leaf slots of one wide node)
 
 // The conservative slot test.  With y = RN(1/d): q~ = RN(RN(p - o) * y) and the exact q = RN(RN(p - o) / d)
 // satisfy |q~ - q| <= 2^-22 |q| (three roundings of 2^-24 each), q~ and q have the same sign and vanish together.
@@ -152,9 +155,9 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     unsigned tos = 0;       // top of the stack of interior groups (0: none); older entries in stack[0..sp)
     __attribute__((address_space(3))) unsigned* stack = (__attribute__((address_space(3))) unsigned*)stackLds + threadIdx.x;
     int sp = 0;  // in units of kWideBlock entries
-    // leaf groups still to be opened (LIFO, g0 on top; order is free) and the open leaf's triangle cursor
+    // leaf groups still to be opened (LIFO, g[0] on top; order is free) and the open leaf's triangle cursor
     int groups = 0;
-    unsigned g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+    unsigned g[kWideGroups] = {};  // compile-time indices only: registers
     int cur = -1, curLeaf = 0;
     unsigned raySlot = 0, queueSlot = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
@@ -294,8 +297,9 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                 const int hm = wide_hit_mask(nearx, farx, neary, fary, nearz, farz, ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz);
                 const int lh = hm & lmask, ih = hm & imask;
                 if (lh != 0) {  // park the candidate leaves of this node as one group
-                    g3 = g2; g2 = g1; g1 = g0;
-                    g0 = pack_group(f2i(meta.y), lmask, lh);
+#pragma unroll
+                    for (int k = kWideGroups - 1; k > 0; k--) g[k] = g[k - 1];
+                    g[0] = pack_group(f2i(meta.y), lmask, lh);
                     ++groups;
                 }
                 if (ih != 0) {  // the hit children go on top of the stack as one entry
@@ -332,10 +336,11 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                 if (cur >= 0 || opening) {
                     const __attribute__((address_space(1))) float4v* triAt;
                     if (opening) {
-                        curLeaf = group_take(g0);
+                        curLeaf = group_take(g[0]);
                         triAt = (const __attribute__((address_space(1))) float4v*)s.leafHead + kLeafHeadStrideF4 * (size_t)curLeaf;
-                        if ((g0 & 15u) == 0u) {
-                            g0 = g1; g1 = g2; g2 = g3;
+                        if ((g[0] & 15u) == 0u) {
+#pragma unroll
+                            for (int k = 0; k + 1 < kWideGroups; k++) g[k] = g[k + 1];
                             --groups;
                         }
                     } else {
