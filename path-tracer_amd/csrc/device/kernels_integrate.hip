@@ -132,7 +132,13 @@ __device__ __forceinline__ void emit_extension(const PathBuffers& pb, unsigned p
 // the occlusion flags: the same additions in the same order, only later.  Paths that end at a Lambertian vertex
 // (bounce cap, Russian roulette) wait in the "fin" queue for their shadow rays and are resolved by the next
 // shade call; the host issues one last finals-only call after the loop.
-enum : int { FLAG_PEND_LAMBERT = 4 };  // the previous vertex was Lambertian: its L is still in contrib[] / occ[]
+enum : int { FLAG_PEND_LAMBERT = 4,   // the previous vertex was Lambertian: its L is still in contrib[] / occ[]
+             // One light (every shipped configuration): L = 0 + c0, so L * multTerm (C:2316 / C:2322) is c0 * multTerm and
+             // can be formed when c0 is, and the weight the next hit applies to multTerm (C:2323) can be applied at
+             // once: contrib[] then holds c0 * multTerm, mult[] the multiplied term, the rng dimension rides in the
+             // flags' upper half, and the vertex neither writes hitMul[] nor does the next one read it (32 B per
+             // Lambertian bounce of ~260).  Same operands, same products, formed one kernel earlier.
+             FLAG_FOLDED = 8 };
 
 __device__ __forceinline__ vec3 pending_light(const PathBuffers& pb, unsigned p, int nl) {
     vec3 L{0.0f, 0.0f, 0.0f};
@@ -146,13 +152,20 @@ __device__ __forceinline__ vec3 pending_light(const PathBuffers& pb, unsigned p,
 
 __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams fp, PathBuffers pb, int it, int finalsOnly) {
     const int nl = pb.nLights;
+    const bool fold = nl == 1;  // see FLAG_FOLDED
+    // The "fin" queue of bounce it is written by this call while the one of bounce it-1 is still being read by other
+    // blocks of it (Russian roulette ends paths at every bounce after the fifth): two buffers, by parity.  vP is the
+    // direct mode's vertex cache, idle in path mode, and larger than a queue.
+    int* const qFin[2] = {pb.qAct, (int*)pb.vP};
     // ---- paths that ended at a Lambertian vertex of bounce it-1: their shadow rays are traced now ----
     if (it > 0) {
         const unsigned* cFin = pb.counters + counter_index(it - 1, 1, 0);
         for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < pb.space; i += gridDim.x * kBlock) {
             if (!slot_live(cFin, pb.regionSize, i)) continue;
-            const unsigned p = (unsigned)pb.qAct[i];
-            finish_path(pb, p, xyz(pb.cnst[p]) + xyz(pb.mult[p]) * pending_light(pb, p, nl));  // C:2316
+            const unsigned p = (unsigned)qFin[(it - 1) & 1][i];
+            const float4 c4 = pb.cnst[p];
+            const vec3 L = pending_light(pb, p, nl);
+            finish_path(pb, p, (f2i(c4.w) & FLAG_FOLDED) ? xyz(c4) + L : xyz(c4) + xyz(pb.mult[p]) * L);  // C:2316
         }
     }
     if (finalsOnly) return;
@@ -191,10 +204,14 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams f
                 const bool pendLambert = (flags & FLAG_PEND_LAMBERT) != 0;
                 vec3 L{0.0f, 0.0f, 0.0f};
                 if (pendLambert) L = pending_light(pb, p, nl);
+                const bool folded = (flags & FLAG_FOLDED) != 0;  // L is already times multTerm, mult already weighted
                 if (tri < 0) {
-                    const vec3 result = pendLambert ? cnst + mult * L : cnst + mult * get_background(s, d);
+                    const vec3 result = pendLambert ? (folded ? cnst + L : cnst + mult * L) : cnst + mult * get_background(s, d);
                     finish_path(pb, p, result);
                     alive = false;
+                } else if (folded) {
+                    cnst = cnst + L;                          // C:2322
+                    dim = (unsigned)flags >> 16;
                 } else {
                     if (pendLambert) cnst = cnst + L * mult;  // C:2322
                     const float4 hm = pb.hitMul[p];
@@ -219,7 +236,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams f
                         const float ndl = pt::dot(N, l);
                         const vec3 irradiance = light_factor(ndl, falloff) * xyz(lw);
                         const bool need = ndl > 0.0f;
-                        pb.contrib[(size_t)p * nl + k] = pack((irradiance * texture) * brdf, i2f(need ? 1 : 0));
+                        const vec3 c = (irradiance * texture) * brdf;
+                        pb.contrib[(size_t)p * nl + k] = pack(fold ? c * mult : c, i2f(need ? 1 : 0));
                         pb.occ[(size_t)p * nl + k] = 0;
                         // shadow ray P -> light, (0, dist), C:2303 / C:2428; the lanes here are
                         // exactly the Lambertian vertices, the ballot sees only them
@@ -236,9 +254,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams f
                     if (!done && it > 5) {  // C:2311-2314, no weight compensation
                         if (counter_rand(fp.seedHash, (unsigned)pix, sample, dim++) < .25f) done = true;
                     }
-                    pb.mult[p] = pack(mult, eta);
                     if (done) {
-                        pb.cnst[p] = pack(cnst, i2f(FLAG_PEND_LAMBERT));
+                        if (!fold) pb.mult[p] = pack(mult, eta);
+                        pb.cnst[p] = pack(cnst, i2f(fold ? (FLAG_PEND_LAMBERT | FLAG_FOLDED) : FLAG_PEND_LAMBERT));
                         toFin = true;
                     } else {
                         const float u1 = counter_rand(fp.seedHash, (unsigned)pix, sample, dim++);
@@ -247,8 +265,15 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams f
                         const vec3 sample_brdf = m.Kd / kPI;
                         const float pdf = 1.0f / kPI;
                         emit_extension(pb, p, P, 0.001f, smp);
-                        pb.hitMul[p] = pack((texture * sample_brdf) / pdf, i2f((int)dim));
-                        pb.cnst[p] = pack(cnst, i2f(FLAG_PEND_LAMBERT));  // the next vertex reads currDir = ray.d
+                        const vec3 weight = (texture * sample_brdf) / pdf;
+                        if (fold) {
+                            pb.mult[p] = pack(mult * weight, eta);
+                            pb.cnst[p] = pack(cnst, i2f(FLAG_PEND_LAMBERT | FLAG_FOLDED | (int)(dim << 16)));
+                        } else {
+                            pb.mult[p] = pack(mult, eta);
+                            pb.hitMul[p] = pack(weight, i2f((int)dim));
+                            pb.cnst[p] = pack(cnst, i2f(FLAG_PEND_LAMBERT));  // the next vertex reads currDir = ray.d
+                        }
                         toExt = true;
                     }
                 } else if (m.type == MIPT_MAT_METAL) {
@@ -290,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams f
         const unsigned sExt = wave_append(cNext, pb.regionSize, (i >> 6) % (unsigned)kShards, toExt);
         if (toExt) qNext[sExt] = (int)p;
         const unsigned sFin = wave_append(cFinOut, pb.regionSize, (i >> 6) % (unsigned)kShards, toFin);
-        if (toFin) pb.qAct[sFin] = (int)p;
+        if (toFin) qFin[it & 1][sFin] = (int)p;
     }
 }
 

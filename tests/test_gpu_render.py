@@ -69,6 +69,23 @@ def test_path_mode_vs_oracle(B, ob, sf, name, spp, bounces):
     assert st["rays_closest"] + st["rays_occluded"] > 0
 
 
+def test_deep_paths_are_deterministic_and_match_per_pixel(B, ob, sf):
+    """Russian roulette (cs488.h:2311-2314) ends Lambertian paths at EVERY bounce after the fifth, so the queue of
+    paths that wait for their last shadow rays is written and read by the same shading launch: rendering the same
+    frame twice must give the same bits (it did not while that queue was a single buffer), and since the counter
+    RNG gives the oracle the same paths, all but a handful of pixels agree to rounding"""
+    scene, ctx, orc = setup_scene(B, sf, "cornellbox")
+    cam, ocam = cams(B, ob, sf, "cornellbox", 160, 160)
+    for bounces in (12, -1):
+        a = ctx.render(cam, mode=B.MODE_PATH, spp=8, max_bounces=bounces, seed=3)
+        b = ctx.render(cam, mode=B.MODE_PATH, spp=8, max_bounces=bounces, seed=3)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "two renders of the same frame differ"
+        ref = orc.pathtrace(ocam, spp=8, max_bounces=bounces, rng_mode=1, seed=3)
+        rel = np.abs(a.astype(np.float64) - ref).max(axis=2) / np.maximum(ref.astype(np.float64).max(axis=2), 1e-6)
+        assert (rel > 1e-4).mean() < 0.002, ((rel > 1e-4).mean(), "fraction of pixels off by more than 1e-4")
+        compare(a, ref, 1e-3, 1e-5)
+
+
 def test_ray_counts_match_oracle(B, ob, sf):
     scene, ctx, orc = setup_scene(B, sf, "cornellbox")
     cam, ocam = cams(B, ob, sf, "cornellbox", 128, 96)
