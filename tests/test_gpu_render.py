@@ -86,6 +86,25 @@ def test_deep_paths_are_deterministic_and_match_per_pixel(B, ob, sf):
         compare(a, ref, 1e-3, 1e-5)
 
 
+@pytest.mark.parametrize("name", ["cornellbox", "testObj"])
+def test_two_lights_path_and_direct(B, ob, sf, name):
+    """two point lights: the light loop of shade / shade_pathtrace (cs488.h:2287-2310, 2418-2436) sums L over the
+    lights in order before it meets multTerm -- the single-light folding of k_shade_path must stay out of the way"""
+    arrays = sf.load_scene_arrays(name)
+    env = sf.procedural_env(128)
+    lights = ((3.0, 3.0, 3.0, 1000.0, 1000.0, 1000.0), (-1.5, 2.0, 2.5, 300.0, 500.0, 700.0))
+    scene = sf.product_scene_from_mesh_arrays(*arrays, env=env, lights=lights)
+    ctx = B.Context(scene, device=0)
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays, env=env, lights=lights)
+    cam, ocam = cams(B, ob, sf, name, 160, 120)
+    compare(ctx.render(cam, mode=B.MODE_DIRECT), orc.raytrace(ocam), 1e-5, 1e-6)
+    a = ctx.render(cam, mode=B.MODE_PATH, spp=4, max_bounces=10, seed=7)
+    ref = orc.pathtrace(ocam, spp=4, max_bounces=10, rng_mode=1, seed=7)
+    rel = np.abs(a.astype(np.float64) - ref).max(axis=2) / np.maximum(ref.astype(np.float64).max(axis=2), 1e-6)
+    assert (rel > 1e-4).mean() < 0.003, (rel > 1e-4).mean()
+    compare(a, ref, 2e-3, 1e-4)
+
+
 def test_ray_counts_match_oracle(B, ob, sf):
     scene, ctx, orc = setup_scene(B, sf, "cornellbox")
     cam, ocam = cams(B, ob, sf, "cornellbox", 128, 96)
