@@ -594,7 +594,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.nodeRight = (const int*)(base + oRight);
     c->ds.btLinks = (const int4*)(base + oBt);
     c->ds.btOk = s->btOk ? 1 : 0;
-    c->ds.nWide = s->wideOk ? s->nWide : 0;
+    // k_trace_wide addresses leafHead and leafTris with 32-bit offsets from leafTris
+    c->ds.nWide = (s->wideOk && oLeafHead + szLeafHead - oLeaf < ((size_t)1 << 32)) ? s->nWide : 0;
     c->ds.nWideTop = s->nWide < ptd::kWideTopNodes ? s->nWide : ptd::kWideTopNodes;
     if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->dTotals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     const unsigned total = q.counts ? prefix[kShards] : q.space;
     const __attribute__((address_space(3))) float4v* topLds = (const __attribute__((address_space(3))) float4v*)top;
     const __attribute__((address_space(1))) float4v* nodesGlobal = (const __attribute__((address_space(1))) float4v*)s.wnodes;
+    const unsigned headOfs = (unsigned)((const char*)s.leafHead - (const char*)s.leafTris);
 
     // lane state
     bool hasRay = false;
@@ -334,18 +335,22 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                 if (COUNT) { nv += (cur >= 0 || opening) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; }
 #endif
                 if (cur >= 0 || opening) {
-                    const __attribute__((address_space(1))) float4v* triAt;
+                    // leafHead and leafTris lie in one arena less than 4 GB apart (checked when the context is made):
+                    // one uniform base, 32-bit offsets
+                    unsigned triOfs;
                     if (opening) {
                         curLeaf = group_take(g[0]);
-                        triAt = (const __attribute__((address_space(1))) float4v*)s.leafHead + kLeafHeadStrideF4 * (size_t)curLeaf;
+                        triOfs = headOfs + (unsigned)curLeaf * (16u * kLeafHeadStrideF4);
                         if ((g[0] & 15u) == 0u) {
 #pragma unroll
                             for (int k = 0; k + 1 < kWideGroups; k++) g[k] = g[k + 1];
                             --groups;
                         }
                     } else {
-                        triAt = (const __attribute__((address_space(1))) float4v*)s.leafTris + 3 * (size_t)cur;
+                        triOfs = ((unsigned)cur << 5) + ((unsigned)cur << 4);  // 48 B per leafTris record
                     }
+                    const __attribute__((address_space(1))) float4v* triAt =
+                        (const __attribute__((address_space(1))) float4v*)((const __attribute__((address_space(1))) char*)s.leafTris + (size_t)triOfs);
                     const float4v q0 = triAt[0], q1 = triAt[1], q2 = triAt[2];
                     if (opening) cur = f2i(q2.w);
 #if !PT_DIAG_UTIL
