@@ -130,6 +130,8 @@ def main():
                          "averages of a rocprofv3 run of this command are those of the headline workload")
     ap.add_argument("--spp", type=int, default=SPP, help="samples per GPU per step (default 16 = BASELINE configs[3]; other "
                                                          "values are for studying launch-size effects, not the headline)")
+    ap.add_argument("--bvh", choices=("reference", "all-axes"), default="reference",
+                    help="all-axes: the three-axis SAH build (SURVEY 8(f).1), NOT the reference's tree and not the headline")
     ap.add_argument("--detail", type=int, default=1, help="sponza-standin tessellation (1: 65,536 tris, 2: 256,768)")
     args = ap.parse_args()
 
@@ -154,7 +156,7 @@ def main():
     # ---- scene: host-side load/build, then one arena upload ----
     arrays = sf.sponza_standin(args.detail)
     env = sf.procedural_env(1024)
-    scene = sf.product_scene_from_mesh_arrays(*arrays, env=env, lights=sf.SPONZA_LIGHT)
+    scene = sf.product_scene_from_mesh_arrays(*arrays, env=env, lights=sf.SPONZA_LIGHT, all_axes=args.bvh == "all-axes")
     stream = torch.cuda.current_stream(dev)
     ctx = B.Context(scene, device=local_rank, stream=stream.cuda_stream)
     cam = B.make_camera(W, H, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
@@ -251,7 +253,7 @@ def main():
                                    f"RCCL gather to rank 0" if world > 1 else
                                    f"sponza-standin ({len(arrays[3])} tris, procedural; sponza.obj absent) 1920x1080 "
                                    f"path trace, {BOUNCES} bounces, {args.spp} spp per step, procedural env (uffizi_probe.hdr absent)",
-                       "resolution": [W, H], "bounces": BOUNCES, "spp_per_step": spp_per_step, "seed": SEED,
+                       "bvh": args.bvh, "resolution": [W, H], "bounces": BOUNCES, "spp_per_step": spp_per_step, "seed": SEED,
                        "rays_per_step": total_rays / args.steps,
                        "ms_per_frame_1spp": elapsed_max / args.steps * 1e3 / spp_per_step * world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

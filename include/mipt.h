@@ -195,6 +195,12 @@ void mipt_image_destroy(mipt_image*);
  * C:1412-1558) + StacklessBVH::build links C:1645-1660 + StacklessBVH2::build
  * links C:1713-1730.  Node numbering and leaf order equal the reference's. */
 int mipt_bvh_build(const mipt_mesh* mesh, mipt_bvh** out);
+/* SURVEY 8(f).1, NOT the reference's tree: the same SAH sweep and cost (C:1406-1409, C:1488-1504) along each of the
+ * three axes instead of the largest one only (C:1463), the cheapest split of all wins.  Fewer boxes per ray, but
+ * another node numbering and other leaf boxes: hit distances equal the reference's except where a triangle's own
+ * leaf box decides (floating-point edge cases), ids may differ on exact ties.  Everything downstream (links, scene,
+ * traversals) takes it like the reference's tree. */
+int mipt_bvh_build_all_axes(const mipt_mesh* mesh, mipt_bvh** out);
 int32_t mipt_bvh_num_nodes(const mipt_bvh*);
 int32_t mipt_bvh_num_leaves(const mipt_bvh*);
 int32_t mipt_bvh_depth(const mipt_bvh*);

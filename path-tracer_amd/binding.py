@@ -73,7 +73,7 @@ SYMBOLS = [
     "mipt_image_load", "mipt_image_create", "mipt_image_width", "mipt_image_height", "mipt_image_pixels",
     "mipt_image_save_png", "mipt_image_save_hdr", "mipt_image_save_pfm", "mipt_image_destroy",
     "mipt_scene_cache_save", "mipt_scene_cache_load", "mipt_image_pack_rgb8", "mipt_image_compare", "mipt_pack_rgb8_device",
-    "mipt_bvh_build", "mipt_bvh_num_nodes", "mipt_bvh_num_leaves", "mipt_bvh_depth", "mipt_bvh_max_leaf_size",
+    "mipt_bvh_build", "mipt_bvh_build_all_axes", "mipt_bvh_num_nodes", "mipt_bvh_num_leaves", "mipt_bvh_depth", "mipt_bvh_max_leaf_size",
     "mipt_bvh_node_min", "mipt_bvh_node_max", "mipt_bvh_id_hit", "mipt_bvh_id_miss", "mipt_bvh_leaf_first",
     "mipt_bvh_leaf_count", "mipt_bvh_id_left", "mipt_bvh_id_right", "mipt_bvh_id_parent", "mipt_bvh_id_sibling",
     "mipt_bvh_tri_index", "mipt_bvh_destroy",
@@ -137,6 +137,7 @@ def lib():
     for n in ("mipt_image_save_png", "mipt_image_save_hdr", "mipt_image_save_pfm"):
         getattr(L, n).argtypes = [C.c_char_p, C.c_int32, C.c_int32, fp]
     L.mipt_bvh_build.argtypes = [vp, C.POINTER(vp)]
+    L.mipt_bvh_build_all_axes.argtypes = [vp, C.POINTER(vp)]
     L.mipt_scene_cache_save.argtypes = [C.c_char_p, vp, vp]
     L.mipt_image_pack_rgb8.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint8)]
     L.mipt_image_compare.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t] + [C.POINTER(C.c_double)] * 3
@@ -377,11 +378,11 @@ def save_pfm(path, rgb):
 class BVH:
     """StacklessBVH of the reference (C:1641-1660) behind mipt_bvh_*"""
 
-    def __init__(self, mesh, handle=None):
+    def __init__(self, mesh, handle=None, all_axes=False):
         self.mesh = mesh
         if handle is None:
             handle = C.c_void_p()
-            check(lib().mipt_bvh_build(mesh.h, C.byref(handle)))
+            check((lib().mipt_bvh_build_all_axes if all_axes else lib().mipt_bvh_build)(mesh.h, C.byref(handle)))
         self.h = handle
 
     @property

@@ -195,6 +195,16 @@ int mipt_bvh_build(const mipt_mesh* mesh, mipt_bvh** out) {
     return MIPT_OK;
     MIPT_GUARD_END
 }
+int mipt_bvh_build_all_axes(const mipt_mesh* mesh, mipt_bvh** out) {
+    if (!mesh || !out) { pt::set_error("mipt_bvh_build_all_axes: null argument"); return MIPT_ERR_INVALID; }
+    MIPT_GUARD_BEGIN
+    mipt_bvh* b = new mipt_bvh();
+    int rc = b->bvh.build(&mesh->mesh, true);
+    if (rc != MIPT_OK) { delete b; return rc; }
+    *out = b;
+    return MIPT_OK;
+    MIPT_GUARD_END
+}
 int32_t mipt_bvh_num_nodes(const mipt_bvh* b) { return b ? b->bvh.nodeNum : 0; }
 int32_t mipt_bvh_num_leaves(const mipt_bvh* b) { return b ? b->bvh.leafNum : 0; }
 int32_t mipt_bvh_depth(const mipt_bvh* b) { return b ? b->bvh.depth : 0; }

@@ -16,6 +16,7 @@
 // Structure differs from the reference: one index array partitioned in place,
 // an explicit work stack instead of recursion, one reusable suffix-box buffer
 // instead of two fresh arrays per node.
+#include <algorithm>
 #include <cfloat>
 #include <cstring>
 
@@ -99,7 +100,7 @@ struct Work {
 
 }  // namespace
 
-int StacklessBVH::build(const TriangleMesh* mesh) {
+int StacklessBVH::build(const TriangleMesh* mesh, bool allAxes) {
     const int n = mesh->numTriangles();
     if (n <= 0) {
         set_error("BVH build: mesh has no triangles");
@@ -147,33 +148,56 @@ int StacklessBVH::build(const TriangleMesh* mesh) {
 
         const int cnt = w.count;
         int32_t* idx = b.index.data() + w.first;
-        b.sortAxis(w.box.largestAxis(), w.first, w.first + cnt - 1);
-
-        // suffix[k] = box of idx[k..cnt)
-        Box acc;
-        acc.reset();
-        for (int k = cnt - 1; k >= 1; --k) {
-            acc.fitTriangle(b.pos + (size_t)9 * idx[k]);
-            b.suffix[k] = acc;
-        }
         float minCost = FLT_MAX;
         int bestSplit = -1;  // left gets idx[0..bestSplit]
         Box bestL, bestR;
-        Box left;
-        left.reset();
         const float parentArea = w.box.area();
-        for (int k = 0; k < cnt - 1; ++k) {
-            left.fitTriangle(b.pos + (size_t)9 * idx[k]);
-            const Box& right = b.suffix[k + 1];
-            const float costL = 0.1f + left.area() / parentArea * (k + 1) * 1.0f;
-            const float costR = 0.1f + right.area() / parentArea * (cnt - k - 1) * 1.0f;
-            const float cost = costL + costR;
-            if (cost < minCost) {
-                bestL = left;
-                bestR = right;
-                bestSplit = k;
-                minCost = cost;
+        // the sweep along the current order of idx: the reference's cost, first minimum wins
+        auto sweep = [&]() -> bool {
+            bool improved = false;
+            Box acc;  // suffix[k] = box of idx[k..cnt)
+            acc.reset();
+            for (int k = cnt - 1; k >= 1; --k) {
+                acc.fitTriangle(b.pos + (size_t)9 * idx[k]);
+                b.suffix[k] = acc;
             }
+            Box left;
+            left.reset();
+            for (int k = 0; k < cnt - 1; ++k) {
+                left.fitTriangle(b.pos + (size_t)9 * idx[k]);
+                const Box& right = b.suffix[k + 1];
+                const float costL = 0.1f + left.area() / parentArea * (k + 1) * 1.0f;
+                const float costR = 0.1f + right.area() / parentArea * (cnt - k - 1) * 1.0f;
+                const float cost = costL + costR;
+                if (cost < minCost) {
+                    bestL = left;
+                    bestR = right;
+                    bestSplit = k;
+                    minCost = cost;
+                    improved = true;
+                }
+            }
+            return improved;
+        };
+        if (!allAxes) {
+            b.sortAxis(w.box.largestAxis(), w.first, w.first + cnt - 1);
+            sweep();
+        } else {
+            // quality mode (NOT the reference's tree): the same sweep along each of the three axes, the cheapest
+            // split of all wins; triangles ordered by (key, index), so the tree does not depend on a sort's whims
+            int bestAxis = -1;
+            for (int axis = 0; axis < 3; axis++) {
+                std::sort(idx, idx + cnt, [&](int32_t x, int32_t y) {
+                    const float kx = b.key(x, axis), ky = b.key(y, axis);
+                    return kx < ky || (kx == ky && x < y);
+                });
+                if (sweep()) bestAxis = axis;
+            }
+            if (bestAxis >= 0 && bestAxis != 2)
+                std::sort(idx, idx + cnt, [&](int32_t x, int32_t y) {
+                    const float kx = b.key(x, bestAxis), ky = b.key(y, bestAxis);
+                    return kx < ky || (kx == ky && x < y);
+                });
         }
         const bool leaf = (minCost > (float)cnt * 1.0f) || cnt <= 1;
         if (leaf) {

@@ -81,7 +81,8 @@ public:
     std::vector<int32_t> idLeft, idRight, idParent, idSibling;
     std::vector<int32_t> triIndex;        // all leaves' triList, concatenated in node order
     // preCalc (C:817-831) + BVH::build (C:1562-1595) + link assignment
-    int build(const TriangleMesh* mesh);
+    // allAxes: sweep all three axes per node (a better tree, but not the reference's: new node numbering)
+    int build(const TriangleMesh* mesh, bool allAxes = false);
 };
 
 // flat binary cache of a loaded mesh + built BVH (host/scene_cache.cpp)

@@ -311,3 +311,27 @@ def test_pack_rgb8_and_compare_images(B):
     rmse, ma, mb = B.compare_images(a, b)
     assert abs(rmse - np.sqrt(np.mean((a.astype(np.float64) - b) ** 2))) < 1e-12
     assert abs(ma - a.astype(np.float64).mean()) < 1e-12 and abs(mb - b.astype(np.float64).mean()) < 1e-12
+
+
+def test_all_axes_bvh_is_a_valid_tree_and_cheaper(B, sf):
+    """the three-axis SAH build is not the reference's tree, but it must be a tree of the same kind
+    -- every triangle in exactly one leaf, every box the tight union of what lies below it, preorder links -- so
+    that everything downstream (wide tree, bit-trail links) accepts it, and it should be the better tree"""
+    mesh = B.Mesh.from_arrays(*sf.sponza_standin(1))
+    ref, alt = B.BVH(mesh), B.BVH(mesh, all_axes=True)
+    a = alt.arrays()
+    n = alt.num_nodes
+    pos = mesh.positions().reshape(-1, 3, 3)
+    leaf = a["leaf_count"] > 0
+    assert sorted(a["tri_index"].tolist()) == list(range(mesh.num_triangles))
+    lo, hi = a["node_min"].reshape(-1, 3), a["node_max"].reshape(-1, 3)
+    for i in np.flatnonzero(leaf)[::97]:  # a leaf's box is the tight box of its triangles
+        t = pos[a["tri_index"][a["leaf_first"][i]:a["leaf_first"][i] + a["leaf_count"][i]]].reshape(-1, 3)
+        assert np.array_equal(lo[i], t.min(0)) and np.array_equal(hi[i], t.max(0))
+    inner = np.flatnonzero(~leaf)
+    l, r = a["id_left"][inner], a["id_right"][inner]
+    assert np.array_equal(l, inner + 1) and (r > l).all() and (r < n).all()  # preorder numbering
+    assert np.array_equal(lo[inner], np.minimum(lo[l], lo[r])) and np.array_equal(hi[inner], np.maximum(hi[l], hi[r]))
+    assert alt.depth <= 31 and alt.num_nodes < ref.num_nodes
+    scene = B.Scene(mesh, bvh=alt, lights=sf.SPONZA_LIGHT)
+    assert scene.wide_nodes > 0 and scene.exact_reciprocal
