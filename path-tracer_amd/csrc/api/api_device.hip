@@ -51,6 +51,7 @@ struct mipt_scene {
     std::vector<float4> wnodes, leafBox, leafHead;
     std::vector<int> nodeRight;
     std::vector<int4> btLinks;  // StacklessBVH2 links in device numbering
+    bool hasSpecular = false;   // some material is metal or glass: only then does shade() recurse (C:2455-2490)
     bool btOk = false;
     int nWide = 0;
     bool wideOk = false;
@@ -235,6 +236,7 @@ struct mipt_ctx {
     DevBuf slow;           // rays the wide kernel handed back (trace_closest / trace_occluded)
     bool useWide = true;   // MIPT_TRAVERSAL=walk in the environment forces the literal walk (A/B runs)
     bool useBitTrail = false;  // mipt_context_set_traversal(MIPT_TRAVERSAL_BITTRAIL)
+    bool hasSpecular = false;  // copied from the scene
     // integrator state
     DevBuf pathMem, tileMem, frameMem;
     PathBuffers pb{};
@@ -484,6 +486,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         s->materials.resize((size_t)4 * d->n_materials);
         for (int i = 0; i < d->n_materials; i++) {
             const mipt_material& m = d->materials[i];
+            if (m.type == MIPT_MAT_METAL || m.type == MIPT_MAT_GLASS) s->hasSpecular = true;
             if (m.tex_id >= d->n_textures) { delete s; return fail(MIPT_ERR_INVALID, "material tex_id out of range"); }
             const int ofs = m.tex_id >= 0 ? texOfs[m.tex_id] : -1;
             const int tw = m.tex_id >= 0 ? d->textures[m.tex_id].width : 0;
@@ -594,6 +597,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.nodeRight = (const int*)(base + oRight);
     c->ds.btLinks = (const int4*)(base + oBt);
     c->ds.btOk = s->btOk ? 1 : 0;
+    c->hasSpecular = s->hasSpecular;
     // k_trace_wide addresses leafHead and leafTris with 32-bit offsets from leafTris
     c->ds.nWide = (s->wideOk && oLeafHead + szLeafHead - oLeaf < ((size_t)1 << 32)) ? s->nWide : 0;
     c->ds.nWideTop = s->nWide < ptd::kWideTopNodes ? s->nWide : ptd::kWideTopNodes;
@@ -961,7 +965,9 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
         lastIter = fp.maxBounces;
     } else {
         fp.maxBounces = -1;
-        lastIter = rp->mode == MIPT_MODE_DIRECT ? 6 : 0;  // shade(): level > 5 ends every chain
+        // shade(): level > 5 ends every chain; without a metal or glass material no chain ever starts, and the
+        // six further rounds would only launch kernels over empty queues
+        lastIter = (rp->mode == MIPT_MODE_DIRECT && c->hasSpecular) ? 6 : 0;
     }
     fp.lastIter = lastIter;
     const int nSamples = rp->mode == MIPT_MODE_PATH ? rp->spp : 1;
