@@ -7,6 +7,7 @@
 //               [--mode primary|direct|path] [--spp 16] [--bounces 4] [--seed 1]
 //               [--eye x y z] [--lookat x y z] [--light x y z w] [--device 0]
 //               [--out image.png] [--out-hdr image.hdr] [--out-pfm image.pfm]
+//               [--traversal default|walk|bittrail] [--bvh reference|all-axes]
 //               [--cache scene.miptsc]   mesh + BVH from this flat file when it exists and loads, else parsed and
 //                                        built as usual and then written to it (mipt_scene_cache_*)
 #include <chrono>
@@ -34,7 +35,8 @@ int main(int argc, char** argv) {
     rp.mode = MIPT_MODE_DIRECT;  // the reference's default frame is Raytrace(), cs488.h:2620
     rp.spp = 1; rp.max_bounces = 4; rp.seed = 1; rp.part_count = 1;
     mipt_light light{{3.0f, 3.0f, 3.0f}, {1000.0f, 1000.0f, 1000.0f}};  // main.cpp:26-27
-    int device = 0;
+    int device = 0, traversal = MIPT_TRAVERSAL_DEFAULT;
+    bool allAxes = false;
     for (int i = 1; i < argc; i++) {
         auto need = [&](int k) { if (i + k >= argc) { fprintf(stderr, "missing value after %s\n", argv[i]); exit(2); } };
         std::string a = argv[i];
@@ -50,6 +52,11 @@ int main(int argc, char** argv) {
         else if (a == "--out-hdr") { need(1); outHdr = argv[++i]; }
         else if (a == "--out-pfm") { need(1); outPfm = argv[++i]; }
         else if (a == "--cache") { need(1); cachePath = argv[++i]; }
+        else if (a == "--traversal") {
+            need(1);
+            std::string t = argv[++i];
+            traversal = t == "walk" ? MIPT_TRAVERSAL_THREADED : t == "bittrail" ? MIPT_TRAVERSAL_BITTRAIL : MIPT_TRAVERSAL_DEFAULT;
+        } else if (a == "--bvh") { need(1); allAxes = std::string(argv[++i]) == "all-axes"; }
         else if (a == "--mode") {
             need(1);
             std::string m = argv[++i];
@@ -83,7 +90,7 @@ int main(int argc, char** argv) {
     if (!envPath.empty() && mipt_image_load(envPath.c_str(), &env) != MIPT_OK) die("environment");
     if (!cached) {
         t0 = std::chrono::high_resolution_clock::now();
-        if (mipt_bvh_build(mesh, &bvh) != MIPT_OK) die("BVH build");
+        if ((allAxes ? mipt_bvh_build_all_axes(mesh, &bvh) : mipt_bvh_build(mesh, &bvh)) != MIPT_OK) die("BVH build");
         auto t1 = std::chrono::high_resolution_clock::now();
         printf("Built BVH: %d nodes, %d leaves, depth %d (%.1f ms)\n", mipt_bvh_num_nodes(bvh), mipt_bvh_num_leaves(bvh),
                mipt_bvh_depth(bvh), std::chrono::duration<double, std::milli>(t1 - t0).count());
@@ -97,6 +104,7 @@ int main(int argc, char** argv) {
     mipt_ctx* ctx = nullptr;
     if (mipt_context_create(scene, device, nullptr, &ctx) != MIPT_OK) die("context");
     printf("Arena: %zu bytes on device %d\n", mipt_context_arena_bytes(ctx), device);
+    if (mipt_context_set_traversal(ctx, traversal) != MIPT_OK) die("traversal");
     std::vector<float> rgb((size_t)3 * cam.width * cam.height);
     auto t2 = std::chrono::high_resolution_clock::now();
     if (mipt_render(ctx, &cam, &rp, rgb.data()) != MIPT_OK) die("render");

@@ -10,6 +10,8 @@ The only arithmetic that differs between the two sides is acosf/sinf/cosf
 per image flip at a discontinuity (a shadow edge, Russian roulette, total
 internal reflection), which is what the RMSE bound leaves room for.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -200,3 +202,35 @@ def test_device_rgb8_pack_equals_host_conversion(B, sf):
         ctx.buffer_free(src)
         ctx.buffer_free(dst)
         assert np.array_equal(got[:n], B.pack_rgb8(v)) and (got[n:] == 7).all()
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = (int(v) for v in f.readline().split())
+        scale = float(f.readline())
+        data = np.frombuffer(f.read(), "<f4" if scale < 0 else ">f4").reshape(h, w, 3)
+    return data.astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_headless_cli_renders_and_reuses_its_cache(B, tmp_path):
+    """mipt_render (the headless replacement of main.cpp + CS488Window::start): without a loadable .obj it makes the
+    reference's single triangle (main.cpp:40-44); the frame it writes equals the library's render of that scene bit
+    for bit, a second run takes mesh and BVH from the cache file, and the bit-trail traversal gives the same frame"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(B.LIB_PATH), "mipt_render")
+    pfm, cache = str(tmp_path / "out.pfm"), str(tmp_path / "scene.miptsc")
+    args = [exe, "--width", "96", "--height", "64", "--mode", "path", "--spp", "3", "--bounces", "4", "--seed", "2",
+            "--out-pfm", pfm, "--cache", cache]
+    first = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert first.returncode == 0, first.stderr
+    assert "Built BVH" in first.stdout and os.path.getsize(cache) > 0
+    img = read_pfm(pfm)
+    scene = B.Scene(B.Mesh.single_triangle())
+    want = B.Context(scene, device=0).render(B.default_camera(96, 64), mode=B.MODE_PATH, spp=3, max_bounces=4, seed=2)
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+    second = subprocess.run(args + ["--traversal", "bittrail"], capture_output=True, text=True, timeout=120)
+    assert second.returncode == 0, second.stderr
+    assert "Loaded cache" in second.stdout and "Built BVH" not in second.stdout
+    assert np.array_equal(read_pfm(pfm).view(np.uint32), want.view(np.uint32))
