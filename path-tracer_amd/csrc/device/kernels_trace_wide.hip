@@ -51,6 +51,9 @@ namespace ptd {
 #ifndef PT_TUNE_WIDE_STUCK
 #define PT_TUNE_WIDE_STUCK 8
 #endif
+#ifndef PT_TUNE_WIDE_GREEDY
+#define PT_TUNE_WIDE_GREEDY 0
+#endif
 #ifndef PT_TUNE_WIDE_REFILL_ANYHIT
 #define PT_TUNE_WIDE_REFILL_ANYHIT PT_TUNE_WIDE_REFILL
 #endif
@@ -322,8 +325,14 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         const unsigned long long mCanVisit = __ballot(w >= 0 && groups < kWideGroups);
         unsigned long long mPend = __ballot(cur >= 0 || groups > 0);
         const unsigned long long mStuck = mPend & ~mCanVisit;
+#if PT_TUNE_WIDE_GREEDY
+        // experiment: whichever phase has more lanes to serve runs next
+        if (mPend != 0ull && (__popcll(mPend) >= __popcll(mCanVisit) ||
+                              __popcll(mStuck) >= (ANYHIT ? PT_TUNE_WIDE_STUCK_ANYHIT : PT_TUNE_WIDE_STUCK))) {
+#else
         if (mPend != 0ull && (__popcll(mPend) >= (ANYHIT ? PT_TUNE_WIDE_LEAF_ANYHIT : PT_TUNE_WIDE_LEAF) ||
                               __popcll(mStuck) >= (ANYHIT ? PT_TUNE_WIDE_STUCK_ANYHIT : PT_TUNE_WIDE_STUCK) || mCanVisit == 0ull)) {
+#endif
             do {
                 // One round trip per iteration: a lane either opens the next leaf of its top group (the copy of the
                 // leaf's first triangle in its record) or goes on with the next triangle of its open leaf.  A
@@ -384,7 +393,11 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                 }
                 if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();
                 mPend = __ballot(cur >= 0 || groups > 0);
+#if PT_TUNE_WIDE_GREEDY
+            } while (mPend != 0ull && __popcll(mPend) >= __popcll(__ballot(w >= 0 && groups < kWideGroups)));
+#else
             } while (__popcll(mPend) >= (ANYHIT ? PT_TUNE_WIDE_KEEP_ANYHIT : PT_TUNE_WIDE_KEEP));
+#endif
         }
     }
 #undef PT_FINISH
