@@ -46,3 +46,25 @@ def spread(v):
 morton = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
 k = np.argsort(octant * (1 << 30) + morton, kind="stable")
 timed(o[k], d[k], "sorted: octant, Morton(origin)")
+
+# the same sorted rays, but the 64-ray blocks (what one wavefront takes at a time) in random order: coherent inside
+# a wavefront, while the wavefronts that run at the same time work in unrelated parts of the scene
+os_, ds_ = o[k], d[k]
+blocks = rng.permutation(n // 64)
+idx = (blocks[:, None] * 64 + np.arange(64)[None, :]).reshape(-1)
+timed(os_[idx], ds_[idx], "sorted inside shuffled 64-ray blocks")
+blocks = rng.permutation(n // 1024)
+idx = (blocks[:, None] * 1024 + np.arange(1024)[None, :]).reshape(-1)
+timed(os_[idx], ds_[idx], "sorted inside shuffled 1024-ray blocks")
+
+# primary rays of the bench camera (8 frames' worth), in pixel order, in shuffled 64-ray blocks, fully shuffled
+cam = B.make_camera(1920, 1080, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
+po, pd = ctx.eye_rays(cam)
+po, pd = np.tile(po, (8, 1)), np.tile(pd, (8, 1))
+n = len(po)
+timed(po, pd, "primary rays, pixel order")
+blocks = rng.permutation(n // 64)
+idx = (blocks[:, None] * 64 + np.arange(64)[None, :]).reshape(-1)
+timed(po[idx], pd[idx], "primary rays, shuffled 64-ray blocks")
+idx = rng.permutation(n)
+timed(po[idx], pd[idx], "primary rays, fully shuffled")
