@@ -268,6 +268,15 @@ int mipt_trace(mipt_ctx* ctx, const float* ray_o, const float* ray_d, size_t n, 
 /* the same with DEVICE pointers on the context's stream; no synchronisation.
  * rays: n x {o.xyz, tmin, d.xyz, tmax} (32 B); hits: n x {tri_id, t, beta, gamma} (16 B). */
 int mipt_trace_device(mipt_ctx* ctx, const void* rays_dev, size_t n, void* hits_dev);
+/* mipt_trace_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same kernels and bit-identical results, but the launch
+ * cursors and the list of rays the wide traversal hands back live in a file-scope __device__ array of the library
+ * (4 MiB + 256 B per GPU, held until the process ends) instead of memory the context allocates: this call performs
+ * no hipMalloc / hipFree / event creation.  At most MIPT_NOALLOC_MAX_RAYS rays per call (MIPT_ERR_LIMIT beyond).
+ * Every call on a GPU shares that GPU's array: calls that overlap in time on one device (two contexts, two streams)
+ * race; calls on one stream are ordered.  HIP-event profiling (mipt_context_set_profiling) does not cover it. */
+#define MIPT_NOALLOC_MAX_RAYS 1048576
+int mipt_trace_device_noalloc(mipt_ctx* ctx, const void* rays_dev, size_t n, void* hits_dev);
 /* StacklessBVH::isHit, C:1684-1705 (any-hit), as Scene::isHit uses it for
  * shadow rays, C:2056-2068.  HOST pointers; per-ray tmin/tmax. */
 int mipt_occluded(mipt_ctx* ctx, const float* ray_o, const float* ray_d, const float* tmin, const float* tmax,

@@ -79,7 +79,7 @@ SYMBOLS = [
     "mipt_bvh_tri_index", "mipt_bvh_destroy",
     "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_destroy", "mipt_scene_exact_reciprocal", "mipt_scene_wide_nodes",
     "mipt_context_create", "mipt_context_destroy", "mipt_context_arena_bytes",
-    "mipt_trace", "mipt_trace_device", "mipt_occluded", "mipt_eye_rays", "mipt_background",
+    "mipt_trace", "mipt_trace_device", "mipt_trace_device_noalloc", "mipt_occluded", "mipt_eye_rays", "mipt_background",
     "mipt_selftest_fast_division", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
     "mipt_render_device", "mipt_render", "mipt_context_synchronize", "mipt_context_set_profiling",
     "mipt_context_set_counting", "mipt_context_get_stats", "mipt_context_reset_stats", "mipt_context_set_traversal",
@@ -154,6 +154,7 @@ def lib():
     L.mipt_context_arena_bytes.restype = C.c_size_t
     L.mipt_trace.argtypes = [vp, fp, fp, C.c_size_t, C.c_float, C.c_float, ip, fp, fp, fp]
     L.mipt_trace_device.argtypes = [vp, vp, C.c_size_t, vp]
+    L.mipt_trace_device_noalloc.argtypes = [vp, vp, C.c_size_t, vp]
     L.mipt_occluded.argtypes = [vp, fp, fp, fp, fp, C.c_size_t, C.POINTER(C.c_uint8)]
     L.mipt_eye_rays.argtypes = [vp, C.POINTER(Camera), C.c_size_t, C.c_size_t, fp, fp]
     L.mipt_background.argtypes = [vp, fp, C.c_size_t, fp]
@@ -486,6 +487,12 @@ class Context:
         rec = np.empty((n, 10), np.float32) if want_hitrec else None
         check(lib().mipt_trace(self.h, _fp(o), _fp(d), n, tmin, tmax, _ip(tri), _fp(t), _fp(bary), _fp(rec)))
         return (tri, t, bary, rec) if want_hitrec else (tri, t, bary)
+
+    def trace_device(self, rays_ptr, n, hits_ptr, noalloc=False):
+        """device pointers, asynchronous on the context's stream: rays n x {o.xyz, tmin, d.xyz, tmax}, hits n x
+        {tri_id, t, beta, gamma}; noalloc: the entry point that takes its scratch from the library's static array"""
+        f = lib().mipt_trace_device_noalloc if noalloc else lib().mipt_trace_device
+        check(f(self.h, C.c_void_p(rays_ptr), n, C.c_void_p(hits_ptr)))
 
     def occluded(self, ray_o, ray_d, tmin, tmax):
         o = np.ascontiguousarray(ray_o, dtype=np.float32).reshape(-1, 3)

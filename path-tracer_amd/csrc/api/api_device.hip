@@ -8,6 +8,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <queue>
 #include <string>
 #include <vector>
@@ -37,6 +38,31 @@ unsigned pcg_hash_host(unsigned v) {
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+}  // namespace
+
+// ---- scratch of the entry point that allocates nothing (mipt_trace_device_noalloc) ----
+// What mipt_trace_device takes from hipMalloc'd memory (the launch cursors and the list of rays k_trace_wide hands
+// back, mipt_ctx::slow) lives here instead, in the library's own image: every GPU the library runs on holds its own
+// copy at its own address until the process ends.  Layout: words 0 / 1 = count and second-launch cursor of the list,
+// word 32 = the launch cursor (a 128-B line of its own), bytes 256.. = the list, one int per ray.
+constexpr size_t kNoAllocMaxRays = (size_t)1 << 20;
+constexpr size_t kNoAllocHeaderBytes = 256;
+static __device__ __align__(256) unsigned char scratch[kNoAllocHeaderBytes + sizeof(int) * kNoAllocMaxRays];
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratchMutex;
+void* g_scratchPtr[kMaxDevices] = {};  // device address of `scratch` per GPU; the array's NAME is only a host-side stand-in
+// once per device, with that device current (mipt_context_create)
+int resolve_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) { pt::set_error("device index beyond the library's table"); return MIPT_ERR_LIMIT; }
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (g_scratchPtr[device]) return MIPT_OK;
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) { pt::set_error("hipGetSymbolAddress(scratch) returned null"); return MIPT_ERR_DEVICE; }
+    g_scratchPtr[device] = p;
+    return MIPT_OK;
+}
 }  // namespace
 
 // host copy of a validated scene
@@ -234,6 +260,7 @@ struct mipt_ctx {
     // scratch of the host-pointer entry points
     DevBuf sRays, sHits, sOut, sAux, sAux2;
     DevBuf slow;           // rays the wide kernel handed back (trace_closest / trace_occluded)
+    unsigned char* scratch = nullptr;  // this GPU's copy of the file-scope `scratch` array (mipt_trace_device_noalloc)
     bool useWide = true;   // MIPT_TRAVERSAL=walk in the environment forces the literal walk (A/B runs)
     bool useBitTrail = false;  // mipt_context_set_traversal(MIPT_TRAVERSAL_BITTRAIL)
     bool hasSpecular = false;  // copied from the scene
@@ -534,8 +561,13 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MIPT_ERR_DEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(MIPT_ERR_DEVICE, "device index out of range");
     HIP_TRY(hipSetDevice(device));
+    {
+        const int rcs = resolve_scratch(device);  // the no-alloc entry point's buffer on this GPU
+        if (rcs != MIPT_OK) return rcs;
+    }
     mipt_ctx* c = new mipt_ctx();
     c->device = device;
+    c->scratch = (unsigned char*)g_scratchPtr[device];
     if (const char* tv = getenv("MIPT_TRAVERSAL")) {  // A/B runs without touching the caller: walk | bittrail
         c->useWide = std::string(tv) != "walk";
         c->useBitTrail = std::string(tv) == "bittrail" && s->btOk;
@@ -761,6 +793,39 @@ int mipt_trace_device(mipt_ctx* c, const void* rays_dev, size_t n, void* hits_de
     if (n == 0) return MIPT_OK;
     HIP_TRY(hipSetDevice(c->device));
     trace_closest(c, (const float4*)rays_dev, nullptr, dense(n), nullptr, (float4*)hits_dev);
+    c->acc.rays_closest += n;
+    HIP_TRY(hipGetLastError());
+    return MIPT_OK;
+}
+
+// mipt_trace_device for callers that cannot allocate: same kernels, same results, but the launch cursors and the list
+// of handed-back rays come from this GPU's copy of `scratch` (c->scratch, resolved with hipGetSymbolAddress when the
+// context was made) instead of hipMalloc'd memory.  No hipMalloc / hipFree / event creation here.  Calls on one GPU
+// share that GPU's array: two that overlap in time (two contexts or streams on the same device) race.
+int mipt_trace_device_noalloc(mipt_ctx* c, const void* rays_dev, size_t n, void* hits_dev) {
+    if (!c || (n && (!rays_dev || !hits_dev))) return fail(MIPT_ERR_INVALID, "mipt_trace_device_noalloc: null argument");
+    if (n > kNoAllocMaxRays) return fail(MIPT_ERR_LIMIT, "mipt_trace_device_noalloc: at most 1,048,576 rays per call (the size of the library's static scratch)");
+    if (n == 0) return MIPT_OK;
+    if (!c->scratch) return fail(MIPT_ERR_DEVICE, "mipt_trace_device_noalloc: scratch not resolved on this device");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned* head = (unsigned*)c->scratch;                 // [0] list count, [1] cursor of the list-mode launch
+    unsigned* cursor = head + 32;                           // cursor of the main launch
+    int* list = (int*)(c->scratch + kNoAllocHeaderBytes);   // queue slots of the handed-back rays, at most n
+    HIP_TRY(hipMemsetAsync(head, 0, kNoAllocHeaderBytes, c->stream));  // the array keeps the last call's contents
+    const float4* rays = (const float4*)rays_dev;
+    float4* hits = (float4*)hits_dev;
+    const QueueView q = dense(n);
+    unsigned long long* cnt = c->counting ? c->dTotals + 2 : nullptr;
+    count_launch(c, 0);
+    if (c->useBitTrail) {
+        launch_trace_bittrail_closest(c->stream, c->ds, rays, nullptr, q, hits, cnt);
+    } else if (c->ds.nWide > 0 && c->useWide) {
+        launch_trace_wide_closest(c->stream, c->ds, rays, nullptr, q, cursor, hits, cnt, head, list);
+        launch_trace_slow_closest(c->stream, c->ds, rays, nullptr, hits, cnt, list, head);
+        launch_trace_closest(c->stream, c->ds, rays, nullptr, QueueView{nullptr, 0u, q.space}, head + 1, hits, cnt, list, head);
+    } else {
+        launch_trace_closest(c->stream, c->ds, rays, nullptr, q, cursor, hits, cnt);
+    }
     c->acc.rays_closest += n;
     HIP_TRY(hipGetLastError());
     return MIPT_OK;

@@ -1,0 +1,64 @@
+"""mipt_trace_device_noalloc -- the entry point that allocates nothing (include/mipt.h) -- against
+mipt_trace_device, through the C-ABI, bit for bit: two calls in a row on one context, the second with a smaller
+input (the library's static scratch keeps the first call's contents), with rays that the wide traversal hands back
+(zero direction components: the list in the scratch is used) and the size limit's error."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(sf, B, ctx, n, seed):
+    rng = np.random.default_rng(seed)
+    o = (rng.uniform(-1.0, 1.0, (n, 3)) * 0.5 + np.array([0, 0.1, 0])).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    k = max(1, n // 50)
+    d[:k, rng.integers(0, 3)] = 0.0                     # handed back to k_trace_slow / k_trace
+    d[k:2 * k] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, k)]
+    rays = np.empty((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o, 1e-4, d, B.FLT_MAX
+    return rays
+
+
+@pytest.mark.parametrize("name", ["sponza-standin-trace", "cornellbox"])
+def test_noalloc_entry_matches_trace_device_on_two_calls_in_a_row(B, ob, sf, name):
+    arrays = sf.sponza_standin(1) if name == "sponza-standin-trace" else sf.load_scene_arrays(name)
+    scene = sf.product_scene_from_mesh_arrays(*arrays)
+    ctx = B.Context(scene, device=0)
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+    n_max = 300000
+    d_rays = ctx.buffer_alloc(n_max * 32)
+    d_hits = ctx.buffer_alloc(n_max * 16)
+    d_hits2 = ctx.buffer_alloc(n_max * 16)
+    try:
+        for n, seed in ((n_max, 1), (4097, 2), (1, 3)):      # the second and third calls are smaller than the first
+            rays = _rays(sf, B, ctx, n, seed)
+            ctx.buffer_upload(d_rays, rays)
+            ctx.buffer_upload(d_hits, np.full((n, 4), -7.0, np.float32))
+            ctx.buffer_upload(d_hits2, np.full((n, 4), -9.0, np.float32))
+            ctx.trace_device(d_rays, n, d_hits)
+            ctx.trace_device(d_rays, n, d_hits2, noalloc=True)
+            a = ctx.buffer_download(d_hits, (n, 4)).view(np.uint32)
+            b = ctx.buffer_download(d_hits2, (n, 4)).view(np.uint32)
+            assert np.array_equal(a, b), f"{name}: n={n}: {(a != b).any(axis=1).sum()} rays differ"
+            if n <= 4097:  # and both equal the oracle (bit-exact: id, t, beta, gamma)
+                otri, ot, obary = orc.intersect(rays[:, 0:3], rays[:, 4:7], 1e-4, B.FLT_MAX)
+                assert np.array_equal(b[:, 0].view(np.int32), otri)
+                assert np.array_equal(b[:, 1], ot.view(np.uint32))
+                assert np.array_equal(b[:, 2:4], obary.view(np.uint32).reshape(-1, 2))
+        # literal walk and bit-trail take the same entry point
+        for trav in (B.TRAVERSAL_THREADED, B.TRAVERSAL_BITTRAIL, B.TRAVERSAL_DEFAULT):
+            ctx.set_traversal(trav)
+            rays = _rays(sf, B, ctx, 5000, 4)
+            ctx.buffer_upload(d_rays, rays)
+            ctx.trace_device(d_rays, 5000, d_hits)
+            ctx.trace_device(d_rays, 5000, d_hits2, noalloc=True)
+            assert np.array_equal(ctx.buffer_download(d_hits, (5000, 4)).view(np.uint32),
+                                  ctx.buffer_download(d_hits2, (5000, 4)).view(np.uint32))
+        with pytest.raises(B.MiptError, match="at most"):
+            ctx.trace_device(d_rays, (1 << 20) + 1, d_hits2, noalloc=True)
+        ctx.trace_device(d_rays, 0, d_hits2, noalloc=True)   # empty batch: a no-op
+    finally:
+        for p in (d_rays, d_hits, d_hits2):
+            ctx.buffer_free(p)
