@@ -2,31 +2,35 @@
 """bench.py -- Mrays/s of the ray/scene hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json metric: "Mrays/s ... Sponza 1080p path trace; ms/frame
-@1spp", configs[3]): sponza-standin (procedural atrium, 65,536 triangles --
-the real sponza.obj is not in the reference tree), procedural angular-map
-environment (stand-in for uffizi_probe.hdr), 1920x1080, path traced, 4
-bounces, 16 spp, light (0.5,4,1)/1000 W (main.cpp:24).  One step = one 16-spp
-frame per GPU: with N GPUs a step takes 16*N samples of the frame, image tiles
-are interleaved over the ranks (scene replicated per GPU), every rank renders
-its tiles for those samples and the tiles are gathered to rank 0 over RCCL once
-per step.  Per-GPU work per step is therefore fixed ("weak").  The 16 samples
-of a pixel are traced together (33 M paths resident in HBM), nothing is cached
-between samples: every sample regenerates and re-traces its primary rays as
-the reference does.  ms/frame @1spp = ms_per_step / 16 (config.ms_per_frame_1spp).
-A ray = one closest-hit or any-hit traversal (primary, extension and shadow
-rays each count 1).
+N > 1 either way: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or typed as above, in which case this process spawns the N
+ranks itself (before it touches torch or the GPU), waits for them and relays rank 0's JSON line.
 
-The scene arena, accumulation and frame buffers are resident in HBM before the
-timed region.  torch is plumbing only: device buffers, the stream, RCCL.
+Workload (BASELINE.json metric: "Mrays/s ... Sponza 1080p path trace; ms/frame @1spp", configs[3]): sponza-standin
+(procedural atrium, 65,536 triangles -- the real sponza.obj is not in the reference tree), procedural angular-map
+environment (stand-in for uffizi_probe.hdr), 1920x1080, path traced, 4 bounces, 16 spp, light (0.5,4,1)/1000 W
+(main.cpp:24).  One step = ONE 16-spp frame: with N GPUs the frame's tiles are interleaved over the ranks (scene
+replicated per GPU), every rank renders its tiles for the 16 samples and the tiles are gathered to rank 0 over RCCL
+once per step -- the frame is divided, so this is STRONG scaling, as configs[3] is written ("tile-split over 2/4/8").
+For N > 1 the weak-scaling figure (16*N samples per step: per-GPU work fixed) is measured in a second timed loop and
+reported beside it (config.weak_scaling).  The 16 samples of a pixel are traced together (33 M paths resident in HBM
+on one GPU), nothing is cached between samples: every sample regenerates and re-traces its primary rays as the
+reference does.  ms/frame @1spp = ms_per_step / 16 (config.ms_per_frame_1spp).  A ray = one closest-hit or any-hit
+traversal (primary, extension and shadow rays each count 1).
+
+The scene arena, accumulation and frame buffers are resident in HBM before the timed region.  torch is plumbing only:
+device buffers, the stream, RCCL.
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,11 +44,70 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 W, H, BOUNCES, SEED, SPP = 1920, 1080, 4, 1, 16
 TILE_W, TILE_H = 64, 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (256 CUs x 128 FMA lanes x 2 flop x 2.4 GHz)
 
 
 def algorithmic_bytes(rays, node_visits, tri_tests):
     """32 B ray in + 16 B hit out, 32 B per node visit, 36 B per triangle test"""
     return 48 * rays + 32 * node_visits + 36 * tri_tests
+
+
+def algorithmic_flops(node_visits, tri_tests):
+    """27 flop per box test (6 sub, 6 div, 15 cmp/sel), 95 per triangle test"""
+    return 27 * node_visits + 95 * tri_tests
+
+
+def kernel_source_hash():
+    """identity of the kernel sources a PMC summary belongs to: sha256 over the device code, the API that launches it
+    and the build flags.  tools/pmc_summary.py stores it in profiles/traffic.json; counters recorded for other sources
+    are not reported."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "path-tracer_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "device", "*.h*")) + glob.glob(os.path.join(csrc, "pt", "*.hpp")) +
+                   [os.path.join(csrc, "api", "api_device.hip"), os.path.join(csrc, "Makefile")])
+    for f in files:
+        h.update(os.path.relpath(f, csrc).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as children of this process -- which has
+    not imported torch or touched the GPU -- with the environment torch.distributed.run would give them, relay rank 0's
+    output, exit with the worst exit code.  Children are killed by their own pids if one of them fails or overstays."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc, out0 = 0, ""
+    deadline = time.time() + 1500.0
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        for pr in procs:
+            pr.wait(timeout=max(1.0, deadline - time.time()))
+            rc = rc or pr.returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
 
 
 def cpu_baseline(arrays, env, lights, eye, lookat):
@@ -119,7 +182,7 @@ def cpu_baseline_all_cores(detail, budget=10.0):
 def main():
     if len(sys.argv) == 6 and sys.argv[1] == "--cpu-rows":  # a worker of cpu_baseline_all_cores: no torch, no GPU
         print(json.dumps(_cpu_worker((int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])))), flush=True)
-        return
+        return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -128,24 +191,35 @@ def main():
     ap.add_argument("--with-primary", action="store_true",
                     help="also time configs[0] (cornellbox 512x512 primary rays only); off by default so that the kernel "
                          "averages of a rocprofv3 run of this command are those of the headline workload")
-    ap.add_argument("--spp", type=int, default=SPP, help="samples per GPU per step (default 16 = BASELINE configs[3]; other "
+    ap.add_argument("--spp", type=int, default=SPP, help="samples per step (default 16 = BASELINE configs[3]; other "
                                                          "values are for studying launch-size effects, not the headline)")
     ap.add_argument("--bvh", choices=("reference", "all-axes"), default="reference",
                     help="all-axes: the three-axis SAH build (SURVEY 8(f).1), NOT the reference's tree and not the headline")
     ap.add_argument("--detail", type=int, default=1, help="sponza-standin tessellation (1: 65,536 tris, 2: 256,768)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the N-rank plumbing (launcher, rendezvous over gloo, tile gather, barrier, "
+                         "max-over-ranks timing, rank 0's JSON line) with the render replaced by filling the owned pixels: "
+                         "no GPU, no measurement (tests/test_bench_launcher.py)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import scene_fixtures as sf
-    pkg = importlib.import_module("path-tracer_amd")
-    B = pkg.binding
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)  # nothing below has run in this process: no torch import, no GPU call
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    import scene_fixtures as sf
+    pkg = importlib.import_module("path-tracer_amd")
+
+    if args.dry_run:
+        return dry_run(args, rank, world, torch, dist, pkg)
+
+    B = pkg.binding
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -165,41 +239,57 @@ def main():
 
     gatherer = pkg.tiles.TileGather(W, H, rank, world, dev, TILE_W, TILE_H)  # owned pixels -> rank 0, one RCCL gather per step
 
-    spp_per_step = args.spp * world  # one 16-spp frame-equivalent of paths per GPU per step
-    state = {"sample": 0}
-
-    def step():
-        p = B.RenderParams(B.MODE_PATH, spp_per_step, state["sample"], BOUNCES, SEED, rank, world, TILE_W, TILE_H)
-        ctx.render_device(cam, p, accum.data_ptr(), rgb.data_ptr())
-        state["sample"] += spp_per_step
-        gatherer.gather(rgb)  # no-op on one GPU
-
     def sync():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    ctx.reset_stats()
-    ctx.set_profiling(True)  # HIP events around every kernel launch, on the stream the kernels run on
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    st = ctx.stats()
-    ctx.set_profiling(False)
+    def timed_loop(spp_per_step):
+        """W warm-up steps, then exactly K timed steps of spp_per_step samples of the frame (this rank's tiles), each
+        followed by the gather; -> (seconds, stats of the timed steps, index of the first timed sample)"""
+        state = {"sample": 0}
+
+        def step():
+            p = B.RenderParams(B.MODE_PATH, spp_per_step, state["sample"], BOUNCES, SEED, rank, world, TILE_W, TILE_H)
+            ctx.render_device(cam, p, accum.data_ptr(), rgb.data_ptr())
+            state["sample"] += spp_per_step
+            gatherer.gather(rgb)  # no-op on one GPU
+
+        accum.zero_()
+        for _ in range(args.warmup):
+            step()
+        sync()
+        ctx.reset_stats()
+        ctx.set_profiling(True)  # HIP events around every kernel launch, on the stream the kernels run on
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        st = ctx.stats()
+        ctx.set_profiling(False)
+        return elapsed, st, state["sample"] - args.steps * spp_per_step
+
+    def reduce_over_ranks(elapsed, st):
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rays = torch.tensor([float(st["rays_closest"] + st["rays_occluded"])], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        return float(t.item()), float(rays.item())
+
+    # headline: one args.spp-sample frame per step, divided over the ranks (strong scaling; N = 1: the whole frame)
+    spp_per_step = args.spp
+    elapsed, st, first = timed_loop(spp_per_step)
+    elapsed_max, total_rays = reduce_over_ranks(elapsed, st)
 
     # per-kernel visit counts of exactly the same frames (deterministic), outside the timed region
     accum2 = torch.zeros_like(accum)
     rgb2 = torch.zeros_like(rgb)
     ctx.reset_stats()
     ctx.set_counting(True)
-    first = state["sample"] - args.steps * spp_per_step
     for k in range(args.steps):
         p = B.RenderParams(B.MODE_PATH, spp_per_step, first + k * spp_per_step, BOUNCES, SEED, rank, world, TILE_W, TILE_H)
         ctx.render_device(cam, p, accum2.data_ptr(), rgb2.data_ptr())
@@ -207,21 +297,25 @@ def main():
     cnt = ctx.stats()
     ctx.set_counting(False)
     assert cnt["rays_closest"] == st["rays_closest"] and cnt["rays_occluded"] == st["rays_occluded"]
+    del accum2, rgb2
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    rays = torch.tensor([float(st["rays_closest"] + st["rays_occluded"])], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    elapsed_max, total_rays = float(t.item()), float(rays.item())
+    weak = None
+    if world > 1:  # per-GPU work fixed: N frames' worth of samples per step
+        w_elapsed, w_st, _ = timed_loop(args.spp * world)
+        w_max, w_rays = reduce_over_ranks(w_elapsed, w_st)
+        weak = {"value": w_rays / w_max / 1e6, "unit": "Mrays/s", "ms_per_step": w_max / args.steps * 1e3,
+                "spp_per_step": args.spp * world, "scaling": "weak"}
 
     if rank == 0:
         def kernel_line(rays_k, visits, tests, ms, launches):
             byts = algorithmic_bytes(rays_k, visits, tests)
+            flops = algorithmic_flops(visits, tests)
             return {"launches": int(launches), "avg_launch_ms": ms / max(launches, 1),
                     "algorithmic_bytes_per_launch": byts / max(launches, 1), "rays": int(rays_k),
                     "node_visits_per_ray": visits / max(rays_k, 1), "tri_tests_per_ray": tests / max(rays_k, 1),
-                    "achieved_GBs": byts / max(ms, 1e-9) / 1e6, "algorithmic_bytes_per_ray": byts / max(rays_k, 1)}
+                    "achieved_GBs": byts / max(ms, 1e-9) / 1e6, "algorithmic_bytes_per_ray": byts / max(rays_k, 1),
+                    "algorithmic_flops_per_ray": flops / max(rays_k, 1), "achieved_TFLOPs": flops / max(ms, 1e-9) / 1e9,
+                    "compulsory_bytes_per_launch": 52.0 * rays_k / max(launches, 1)}
         kc = kernel_line(st["rays_closest"], cnt["node_visits_closest"], cnt["tri_tests_closest"], st["ms_closest"],
                          st["launches_closest"])
         ko = kernel_line(st["rays_occluded"], cnt["node_visits_occluded"], cnt["tri_tests_occluded"], st["ms_occluded"],
@@ -234,39 +328,57 @@ def main():
                  ("k_trace_bittrail_closest", "k_trace_bittrail_occluded") if tv == "bittrail" else
                  ("k_trace_closest", "k_trace_occluded"))
         dom, dom_name = (kc, names[0]) if st["ms_closest"] >= st["ms_occluded"] else (ko, names[1])
-        traffic, valu_frac, l2_hit = None, None, None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")  # written from rocprofv3 --pmc passes (see profiles/README.md)
+        # PMC counters of the dominant kernel (separate rocprofv3 --pmc passes, tools/pmc_passes.sh): reported only
+        # when they were recorded for THESE kernel sources and this launch shape
+        pmc, pmc_note = {}, None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                rec = json.load(open(tf)).get(dom_name, {})
-                traffic, valu_frac, l2_hit = rec.get("hbm_bytes_per_launch"), rec.get("valu_active_frac"), rec.get("l2_hit_rate")
-            except Exception:
-                traffic = None
+                allrec = json.load(open(tf))
+                if allrec.get("kernel_source_hash") != kernel_source_hash():
+                    pmc_note = "profiles/traffic.json was recorded for other kernel sources: counters withheld"
+                elif world != 1 or args.spp != SPP or args.detail != 1 or args.bvh != "reference":
+                    pmc_note = "profiles/traffic.json was recorded for the default one-GPU workload: counters withheld"
+                else:
+                    pmc = allrec.get(dom_name, {})
+            except Exception as e:
+                pmc_note = f"profiles/traffic.json unreadable: {e}"
+        traffic = pmc.get("hbm_bytes_per_launch")
+        ms_frame = elapsed_max / args.steps * 1e3 / spp_per_step
+        part = f"tiles {TILE_W}x{TILE_H} interleaved over {world} GPUs, one RCCL gather to rank 0 per step" if world > 1 else "one GPU"
         out = {
             "metric": "Mrays/s, sponza-standin 1920x1080 path trace, 16 spp per frame (ms/frame @1spp = ms_per_step/16)",
             "value": total_rays / elapsed_max / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"sponza-standin ({len(arrays[3])} tris, procedural; sponza.obj absent) 1920x1080 "
-                                   f"path trace, {BOUNCES} bounces, {args.spp} spp per GPU per step, procedural env "
-                                   f"(uffizi_probe.hdr absent), tiles {TILE_W}x{TILE_H} interleaved over {world} GPU(s), "
-                                   f"RCCL gather to rank 0" if world > 1 else
-                                   f"sponza-standin ({len(arrays[3])} tris, procedural; sponza.obj absent) 1920x1080 "
-                                   f"path trace, {BOUNCES} bounces, {args.spp} spp per step, procedural env (uffizi_probe.hdr absent)",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"sponza-standin ({len(arrays[3])} tris, procedural; sponza.obj absent) 1920x1080 path "
+                                   f"trace, {BOUNCES} bounces, ONE {args.spp}-spp frame per step, procedural env "
+                                   f"(uffizi_probe.hdr absent), {part}",
                        "bvh": args.bvh, "resolution": [W, H], "bounces": BOUNCES, "spp_per_step": spp_per_step, "seed": SEED,
-                       "rays_per_step": total_rays / args.steps,
-                       "ms_per_frame_1spp": elapsed_max / args.steps * 1e3 / spp_per_step * world},
-            "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom_name,
+                       "rays_per_step": total_rays / args.steps, "ms_per_frame_1spp": ms_frame,
+                       "weak_scaling": weak},
+            "roofline": {"bound": "valu", "achieved": dom["achieved_TFLOPs"], "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom["achieved_TFLOPs"] / FP32_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": dom_name,
+                         "algorithmic_GBs": dom["achieved_GBs"],
+                         "traffic_over_compulsory": (traffic / dom["compulsory_bytes_per_launch"]) if traffic else None,
+                         "valu_issue_occupancy": pmc.get("valu_issue_occupancy"),
+                         "useful_lane_frac": pmc.get("useful_lane_frac"),
+                         "lanes_per_valu_inst": pmc.get("lanes_per_valu_inst"), "l2_hit_rate": pmc.get("l2_hit_rate"),
+                         "pmc_note": pmc_note,
                          "per_kernel": {"k_trace_closest": kc, "k_trace_occluded": ko, "kernel_names": list(names),
                                         "other_ms_total": st["ms_other"], "other_launches": int(st["launches_other"])},
-                         "valu_active_frac": valu_frac, "l2_hit_rate": l2_hit,
-                         "note": "achieved = algorithmic bytes (48 B/ray + 32 B/node visit + 36 B/triangle test) per "
-                                 "launch / average launch duration from HIP events in the timed region (rank 0); node "
-                                 "visits = box tests (4 per visit of a 4-wide node + the exact test of each candidate "
-                                 "leaf). The traversal re-reads a few MB of nodes from LDS/L1/L2, so algorithmic bytes "
-                                 "exceed HBM traffic (`traffic`, PMC) about tenfold and frac can exceed 1: the kernel is "
-                                 "bound by vector-ALU issue (valu_active_frac, PMC), not by HBM"},
+                         "note": "achieved = algorithmic flops per launch (SURVEY 8(d): 27 per box test + 95 per triangle "
+                                 "test; box tests = 4 per visit of a 4-wide node + the exact test of each candidate leaf, "
+                                 "counted by the COUNT instantiation on the same frames) / average launch duration from "
+                                 "HIP events in the timed region (rank 0), against the fp32 vector peak: the traversal is "
+                                 "bound by vector-ALU issue, not by HBM. -ffp-contract=off (bit-exactness) forbids FMA "
+                                 "in the tests, so at most half of that peak is reachable. algorithmic_GBs = SURVEY 8(d)'s "
+                                 "byte formula (48 B/ray + 32 B/box test + 36 B/triangle test) / the same duration: those "
+                                 "bytes are served by LDS / L1 / L2, not HBM, and may exceed the HBM peak. traffic = HBM-side "
+                                 "bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE), "
+                                 "traffic_over_compulsory = traffic / (52 B x rays). valu_issue_occupancy = VALU "
+                                 "instructions x measured issue cost per instruction class / (SIMDs x kernel cycles); "
+                                 "useful_lane_frac = that x lanes_per_valu_inst / 64 (profiles/README.md)"},
         }
         if world == 1 and args.with_primary:
             # primary-only rate of configs[0] (cornellbox 512x512, closest-hit ids), reported beside the
@@ -298,7 +410,44 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def dry_run(args, rank, world, torch, dist, pkg):
+    """the N-rank plumbing on CPU (gloo): every rank fills the pixels it owns as its GPU would, the tiles are gathered to
+    rank 0 once per step, steps are bracketed by barriers, the time is the max over ranks, rank 0 checks the assembled
+    frame and prints the JSON line (value 0: nothing is measured here)"""
+    w, h = 320, 200
+    if world > 1:
+        dist.init_process_group("gloo")
+    g = pkg.tiles.TileGather(w, h, rank, world, torch.device("cpu"), TILE_W, TILE_H)
+    want = torch.arange(w * h * 3, dtype=torch.float32) * 0.25 + 3.0
+    ok = True
+    t0 = None
+    for k in range(args.warmup + args.steps):
+        if k == args.warmup:
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+        rgb = torch.zeros(w * h * 3)
+        rgb.view(-1, 3)[g.idx[rank]] = (want * (k + 1)).view(-1, 3)[g.idx[rank]]
+        g.gather(rgb)
+        if rank == 0:
+            ok = ok and bool(torch.equal(rgb, want * (k + 1)))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - (t0 or time.perf_counter())], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the N-rank plumbing (no GPU, nothing measured)", "value": 0.0, "unit": "Mrays/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / max(args.steps, 1) * 1e3,
+                          "dry_run": True, "frames_assembled_correctly": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

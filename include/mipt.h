@@ -69,6 +69,8 @@ typedef struct mipt_light {
  * interior node, else the leaf owns tri_index[leaf_first[i] ..
  * leaf_first[i]+leaf_count[i]) in BVHNode::triList order (C:1522-1524).
  * Triangle t: pos/nrm[9t..9t+8] (3 vertices x xyz), uv[6t..6t+5], mat_id[t].
+ * A scene is ONE mesh with ONE BVH: the reference's Scene loops over `objects` (C:2060, C:2075, addObject C:2020),
+ * but every configuration it ships adds exactly one; several meshes are merged into one by the caller.
  * env_rgb: Image::pixels of Scene::background after Image::load's vertical
  * flip (C:214-219); may be NULL (env_width = 0): then a lookup returns black
  * (the reference divides by zero, C:2043).
@@ -118,7 +120,10 @@ typedef struct mipt_render_params {
     int32_t mode;
     int32_t spp;           /* samples taken by this call (path mode); direct mode ignores it */
     int32_t sample_offset; /* index of the first sample: progressive rendering continues here */
-    int32_t max_bounces;   /* extension rays per path; <0 = unbounded as in the reference */
+    int32_t max_bounces;   /* extension rays per path; <0 = no cap as in the reference (C:2339-2389), which here means
+                            * at most 64 bounce iterations: a path still alive then (closed metal / glass chains;
+                            * a Lambertian path survives 58 rounds of roulette with probability 0.75^58 = 6e-8) is
+                            * ended as at the cap, a bias below one part in 10^7 on shipped scenes */
     uint32_t seed;
     /* pixel partition for multi-GPU: the image is cut into tiles of
      * tile_w x tile_h pixels; this call renders tile (tx, ty) iff
@@ -225,6 +230,14 @@ void mipt_bvh_destroy(mipt_bvh*);
  * corrupted or from an incompatible machine.  Array CONTENT is validated where it is used (mipt_scene_create). */
 int mipt_scene_cache_save(const char* path, const mipt_mesh* mesh, const mipt_bvh* bvh);
 int mipt_scene_cache_load(const char* path, mipt_mesh** mesh_out, mipt_bvh** bvh_out);
+/* The same with a source tag: free text the writer chooses to say what the cache was built from (mipt_render stores
+ * the fingerprints of the .obj / .mtl files and the BVH mode); a load that passes expect_tag (not NULL) returns
+ * MIPT_ERR_IO for a cache written with another tag, so a stale cache, or one of another scene or tree, is rebuilt
+ * instead of rendered.  mipt_scene_cache_save = tag "", mipt_scene_cache_load = any tag. */
+int mipt_scene_cache_save_tagged(const char* path, const mipt_mesh* mesh, const mipt_bvh* bvh, const char* tag);
+int mipt_scene_cache_load_tagged(const char* path, const char* expect_tag, mipt_mesh** mesh_out, mipt_bvh** bvh_out);
+/* "name:size:fnv1a64" of a file's content ("name:absent" if unreadable), NUL-terminated into out */
+int mipt_file_fingerprint(const char* path, char* out, size_t out_size);
 
 /* Scene::addObject / addLight / background + preCalc, C:2020-2036: fills a
  * mipt_scene_desc that points INTO mesh, bvh and env (keep them alive while
@@ -297,6 +310,34 @@ int mipt_render_device(mipt_ctx* ctx, const mipt_camera* cam, const mipt_render_
                        float* rgb_dev);
 /* convenience: whole image to a HOST buffer (allocates, renders, copies back, synchronises) */
 int mipt_render(mipt_ctx* ctx, const mipt_camera* cam, const mipt_render_params* params, float* rgb_host);
+
+/* ---- one frame over the GPUs of a node (north_star subsystem 4) ----
+ * Replaces the reference's per-frame launch + readback (G:3209-3216) when more than one GPU renders the frame.  A
+ * node holds one context, one HIP stream and one host thread per GPU, the scene arena replicated.  A frame is cut
+ * into tiles (mipt_render_params.tile_w/h), GPU r renders the tiles with (tx + 3*ty) % ngpus == r, and ONE RCCL
+ * collective per call (ncclGather over xGMI) moves the owned tiles to GPU 0, which writes the frame.  The result is
+ * bit-identical to the one-GPU frame (the per-pixel RNG is keyed on the global pixel index).
+ * devices: ngpus device ids, or NULL for 0 .. ngpus-1.  Repeating an id makes ranks share a GPU (rehearsal on a
+ * machine with fewer GPUs): those ranks cannot form an RCCL communicator, so the gather is device-to-device copies;
+ * mipt_node_uses_rccl() tells which transport a node got.  RCCL is loaded (dlopen) when the first node is made.
+ * A node is driven from one host thread at a time. */
+typedef struct mipt_node mipt_node;
+int mipt_node_create(const mipt_scene* scene, int ngpus, const int* devices, mipt_node** out);
+void mipt_node_destroy(mipt_node*);
+int mipt_node_num_gpus(const mipt_node*);
+int mipt_node_uses_rccl(const mipt_node*);
+/* Scene::Raytrace / Scene::Pathtrace (C:2200-2261) of the whole frame; params->part_index / part_count are ignored.
+ * Path mode is progressive across calls as in mipt_render_device: a call with sample_offset > 0 continues the
+ * accumulation of the previous calls (same camera and resolution), sample_offset == 0 starts a new frame.
+ * rgb_host: width*height*3 floats on the HOST, or NULL to leave the frame on GPU 0 (timing runs).  Returns after the
+ * frame is complete on GPU 0 (and copied, if asked). */
+int mipt_node_render(mipt_node*, const mipt_camera* cam, const mipt_render_params* params, float* rgb_host);
+/* sum of the per-GPU statistics (mipt_context_get_stats); last_frame_ms (may be NULL): host wall time of the last
+ * mipt_node_render call */
+int mipt_node_get_stats(mipt_node*, mipt_stats* out, double* last_frame_ms);
+/* convenience: create a node over GPUs 0 .. ngpus-1, render one frame to the host, destroy the node */
+int mipt_render_node(const mipt_scene* scene, const mipt_camera* cam, const mipt_render_params* params, int ngpus,
+                     float* rgb_out_rank0);
 
 /* Device buffers for callers without a GPU allocator of their own (the
  * frame readback of the reference, G:3213-3216, becomes mipt_buffer_download).

@@ -72,7 +72,8 @@ SYMBOLS = [
     "mipt_mesh_texcoords", "mipt_mesh_material_ids", "mipt_mesh_materials", "mipt_mesh_textures", "mipt_mesh_destroy",
     "mipt_image_load", "mipt_image_create", "mipt_image_width", "mipt_image_height", "mipt_image_pixels",
     "mipt_image_save_png", "mipt_image_save_hdr", "mipt_image_save_pfm", "mipt_image_destroy",
-    "mipt_scene_cache_save", "mipt_scene_cache_load", "mipt_image_pack_rgb8", "mipt_image_compare", "mipt_pack_rgb8_device",
+    "mipt_scene_cache_save", "mipt_scene_cache_load", "mipt_scene_cache_save_tagged", "mipt_scene_cache_load_tagged", "mipt_file_fingerprint",
+    "mipt_image_pack_rgb8", "mipt_image_compare", "mipt_pack_rgb8_device",
     "mipt_bvh_build", "mipt_bvh_build_all_axes", "mipt_bvh_num_nodes", "mipt_bvh_num_leaves", "mipt_bvh_depth", "mipt_bvh_max_leaf_size",
     "mipt_bvh_node_min", "mipt_bvh_node_max", "mipt_bvh_id_hit", "mipt_bvh_id_miss", "mipt_bvh_leaf_first",
     "mipt_bvh_leaf_count", "mipt_bvh_id_left", "mipt_bvh_id_right", "mipt_bvh_id_parent", "mipt_bvh_id_sibling",
@@ -83,6 +84,8 @@ SYMBOLS = [
     "mipt_selftest_fast_division", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
     "mipt_render_device", "mipt_render", "mipt_context_synchronize", "mipt_context_set_profiling",
     "mipt_context_set_counting", "mipt_context_get_stats", "mipt_context_reset_stats", "mipt_context_set_traversal",
+    "mipt_node_create", "mipt_node_destroy", "mipt_node_num_gpus", "mipt_node_uses_rccl", "mipt_node_render",
+    "mipt_node_get_stats", "mipt_render_node",
 ]
 
 _lib = None
@@ -143,6 +146,9 @@ def lib():
     L.mipt_image_compare.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t] + [C.POINTER(C.c_double)] * 3
     L.mipt_pack_rgb8_device.argtypes = [vp, vp, C.c_size_t, vp]
     L.mipt_scene_cache_load.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(vp)]
+    L.mipt_scene_cache_save_tagged.argtypes = [C.c_char_p, vp, vp, C.c_char_p]
+    L.mipt_scene_cache_load_tagged.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(vp)]
+    L.mipt_file_fingerprint.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.mipt_scene_exact_reciprocal.argtypes = [vp]
     L.mipt_scene_exact_reciprocal.restype = C.c_int32
     L.mipt_scene_wide_nodes.argtypes = [vp]
@@ -172,6 +178,14 @@ def lib():
     L.mipt_context_set_traversal.argtypes = [vp, C.c_int]
     L.mipt_context_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mipt_context_reset_stats.argtypes = [vp]
+    L.mipt_node_create.argtypes = [vp, C.c_int, ip, C.POINTER(vp)]
+    L.mipt_node_destroy.argtypes = [vp]
+    L.mipt_node_destroy.restype = None
+    L.mipt_node_num_gpus.argtypes = [vp]
+    L.mipt_node_uses_rccl.argtypes = [vp]
+    L.mipt_node_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), fp]
+    L.mipt_node_get_stats.argtypes = [vp, C.POINTER(Stats), C.POINTER(C.c_double)]
+    L.mipt_render_node.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), C.c_int, fp]
     _lib = L
     return L
 
@@ -417,17 +431,30 @@ class BVH:
             self.h = None
 
 
-def save_scene_cache(path, mesh, bvh):
-    """flat binary cache of a loaded mesh and its built BVH (mipt_scene_cache_save)"""
-    check(lib().mipt_scene_cache_save(os.fsencode(path), mesh.h, bvh.h))
+def save_scene_cache(path, mesh, bvh, tag=None):
+    """flat binary cache of a loaded mesh and its built BVH (mipt_scene_cache_save[_tagged])"""
+    if tag is None:
+        check(lib().mipt_scene_cache_save(os.fsencode(path), mesh.h, bvh.h))
+    else:
+        check(lib().mipt_scene_cache_save_tagged(os.fsencode(path), mesh.h, bvh.h, tag.encode()))
 
 
-def load_scene_cache(path):
-    """-> (Mesh, BVH) as they were saved; raises on a missing, truncated or corrupted file"""
+def load_scene_cache(path, expect_tag=None):
+    """-> (Mesh, BVH) as they were saved; raises on a missing, truncated or corrupted file, and -- when expect_tag is
+    given -- on a cache that was written with another source tag"""
     mh, bh = C.c_void_p(), C.c_void_p()
-    check(lib().mipt_scene_cache_load(os.fsencode(path), C.byref(mh), C.byref(bh)))
+    if expect_tag is None:
+        check(lib().mipt_scene_cache_load(os.fsencode(path), C.byref(mh), C.byref(bh)))
+    else:
+        check(lib().mipt_scene_cache_load_tagged(os.fsencode(path), expect_tag.encode(), C.byref(mh), C.byref(bh)))
     mesh = Mesh(mh)
     return mesh, BVH(mesh, bh)
+
+
+def file_fingerprint(path):
+    buf = C.create_string_buffer(512)
+    check(lib().mipt_file_fingerprint(os.fsencode(path), buf, 512))
+    return buf.value.decode()
 
 
 class Scene:
@@ -584,3 +611,53 @@ class Context:
         if getattr(self, "h", None) and _lib is not None:
             _lib.mipt_context_destroy(self.h)
             self.h = None
+
+
+class Node:
+    """One frame over the GPUs of a node (mipt_node_*): a context, stream and host thread per GPU, tiles gathered to
+    GPU 0 with one RCCL collective per call.  devices: list of device ids (repeats = ranks sharing a GPU)."""
+
+    def __init__(self, scene, ngpus=None, devices=None):
+        self.scene = scene
+        if devices is not None:
+            devs = np.ascontiguousarray(devices, dtype=np.int32)
+            ngpus = int(devs.size)
+        else:
+            devs = None
+        h = C.c_void_p()
+        check(lib().mipt_node_create(scene.h, int(ngpus), _ip(devs), C.byref(h)))
+        self.h = h
+
+    @property
+    def num_gpus(self):
+        return lib().mipt_node_num_gpus(self.h)
+
+    @property
+    def uses_rccl(self):
+        return bool(lib().mipt_node_uses_rccl(self.h))
+
+    def render(self, cam, mode=MODE_PATH, spp=1, sample_offset=0, max_bounces=-1, seed=1, tile_w=0, tile_h=0, readback=True):
+        p = RenderParams(mode, spp, sample_offset, max_bounces, seed, 0, 1, tile_w, tile_h)
+        rgb = np.zeros((cam.height, cam.width, 3), np.float32) if readback else None
+        check(lib().mipt_node_render(self.h, C.byref(cam), C.byref(p), _fp(rgb)))
+        return rgb
+
+    def stats(self):
+        s, ms = Stats(), C.c_double()
+        check(lib().mipt_node_get_stats(self.h, C.byref(s), C.byref(ms)))
+        d = {k: getattr(s, k) for k, _ in Stats._fields_}
+        d["last_frame_ms"] = ms.value
+        return d
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mipt_node_destroy(self.h)
+            self.h = None
+
+
+def render_node(scene, cam, ngpus, mode=MODE_PATH, spp=1, sample_offset=0, max_bounces=-1, seed=1, tile_w=0, tile_h=0):
+    """mipt_render_node: node over GPUs 0..ngpus-1, one frame, host image"""
+    p = RenderParams(mode, spp, sample_offset, max_bounces, seed, 0, 1, tile_w, tile_h)
+    rgb = np.zeros((cam.height, cam.width, 3), np.float32)
+    check(lib().mipt_render_node(scene.h, C.byref(cam), C.byref(p), int(ngpus), _fp(rgb)))
+    return rgb

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <string>
@@ -82,6 +83,27 @@ struct mipt_scene {
     int nWide = 0;
     bool wideOk = false;
 };
+
+// Is the threaded tree a proper binary tree (every interior node's idHit = its left child, that child's idMiss = the
+// right child, both further on in preorder, every node but the root with exactly one parent)?  The bit-trail links
+// and k_trace_slow's right-child table need exactly this; the box planes play no part in it.
+static bool is_binary_tree(const mipt_scene_desc* d) {
+    const int n = d->n_nodes;
+    std::vector<char> seen((size_t)n, 0);
+    seen[0] = 1;
+    for (int i = 0; i < n; i++) {
+        if (d->leaf_count[i] > 0) continue;
+        const int l = d->id_hit[i];
+        if (!(l > i && l < n)) return false;
+        const int r = d->id_miss[l];
+        if (!(r > l && r < n)) return false;
+        if (seen[l] || seen[r]) return false;
+        seen[l] = seen[r] = 1;
+    }
+    for (int i = 0; i < n; i++)
+        if (!seen[i]) return false;
+    return true;
+}
 
 // Builds the 4-wide node array from the threaded binary tree: a wide node stands for a binary interior node, its (up
 // to 4) slots are that node's grandchildren, a child that is a leaf taking one slot itself (or, by default, the
@@ -285,6 +307,20 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+// nothing may throw across the C boundary: every extern "C" body that allocates host memory runs inside this
+template <class F>
+int guarded(const char* what, F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(MIPT_ERR_NOMEM, std::string(what) + ": out of host memory");
+    } catch (const std::exception& e) {
+        return fail(MIPT_ERR_INVALID, std::string(what) + ": " + e.what());
+    } catch (...) {
+        return fail(MIPT_ERR_INVALID, std::string(what) + ": unknown exception");
+    }
+}
+
 struct Timer {
     mipt_ctx* c;
     hipEvent_t a = nullptr, b = nullptr;
@@ -397,8 +433,9 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
     if (d->n_textures < 0 || (d->n_textures && !d->textures)) return fail(MIPT_ERR_INVALID, "bad textures");
     if ((d->env_width > 0) != (d->env_height > 0) || (d->env_width > 0 && !d->env_rgb))
         return fail(MIPT_ERR_INVALID, "bad environment image");
-    try {
-        mipt_scene* s = new mipt_scene();
+    return guarded("mipt_scene_create", [&]() -> int {
+        std::unique_ptr<mipt_scene> owner(new mipt_scene());
+        mipt_scene* s = owner.get();
         const int n = d->n_nodes;
         // Link validation.  Preorder threading means every link points forward
         // (or to 0 = done); enforcing that here guarantees that every walk on
@@ -445,16 +482,16 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         for (int i = 0; i < n; i++) {
             const int miss = d->id_miss[i], hit = d->id_hit[i];
             const int cnt = d->leaf_count[i], first = d->leaf_first[i];
-            if (!(miss == 0 || (miss > i && miss < n))) { delete s; return fail(MIPT_ERR_INVALID, "id_miss must point forward or be 0"); }
+            if (!(miss == 0 || (miss > i && miss < n))) { return fail(MIPT_ERR_INVALID, "id_miss must point forward or be 0"); }
             int link;
             if (cnt > 0) {
-                if (hit != miss) { delete s; return fail(MIPT_ERR_INVALID, "a leaf's id_hit must equal its id_miss"); }
-                if (first < 0 || (long long)first + cnt > d->n_tri_index) { delete s; return fail(MIPT_ERR_INVALID, "leaf range out of tri_index"); }
+                if (hit != miss) { return fail(MIPT_ERR_INVALID, "a leaf's id_hit must equal its id_miss"); }
+                if (first < 0 || (long long)first + cnt > d->n_tri_index) { return fail(MIPT_ERR_INVALID, "leaf range out of tri_index"); }
                 link = ~first;
                 for (int k = 0; k < cnt; k++) {
                     const int j = first + k;
                     const int t = d->tri_index[j];
-                    if (t < 0 || t >= d->n_tris || covered[j]) { delete s; return fail(MIPT_ERR_INVALID, "bad tri_index entry"); }
+                    if (t < 0 || t >= d->n_tris || covered[j]) { return fail(MIPT_ERR_INVALID, "bad tri_index entry"); }
                     covered[j] = 1;
                     const float* p = d->pos + (size_t)9 * t;
                     const pt::vec3 p0{p[0], p[1], p[2]}, p1{p[3], p[4], p[5]}, p2{p[6], p[7], p[8]};
@@ -464,7 +501,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
                     s->leafTris[(size_t)3 * j + 2] = make_float4(b.x, b.y, b.z, 0.0f);
                 }
             } else {
-                if (!(hit > i && hit < n)) { delete s; return fail(MIPT_ERR_INVALID, "an interior node's id_hit must point forward"); }
+                if (!(hit > i && hit < n)) { return fail(MIPT_ERR_INVALID, "an interior node's id_hit must point forward"); }
                 link = perm[hit];
             }
             for (int a = 0; a < 3; a++) {
@@ -480,12 +517,12 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
                                                  __builtin_bit_cast(float, perm[miss]), __builtin_bit_cast(float, link));
         }
         for (char cv : covered)
-            if (!cv) { delete s; return fail(MIPT_ERR_INVALID, "tri_index entry not owned by any leaf"); }
+            if (!cv) { return fail(MIPT_ERR_INVALID, "tri_index entry not owned by any leaf"); }
         // slots by largest box first; a tree that this makes deeper than the kernel's stacks falls back to plain grandchildren
         const char* collapse = getenv("MIPT_WIDE_COLLAPSE");  // "pairs": grandchildren only (for comparisons)
         s->wideOk = (!(collapse && !strcmp(collapse, "pairs")) && build_wide(d, s, true)) || build_wide(d, s, false);
         if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear(); s->nWide = 0; }
-        if (s->wideOk) {  // build_wide has verified the binary tree: right child = where the left subtree's walk exits
+        if (is_binary_tree(d)) {  // right child = where the left subtree's walk exits; independent of the wide tree and of the planes
             s->nodeRight.assign((size_t)n, 0);
             s->btLinks.assign((size_t)n, make_int4(0, 0, 0, 0));  // root: idParent = idSibling = 0, C:1716-1717
             std::vector<int> depthOf((size_t)n, 0);
@@ -506,7 +543,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         std::vector<int> texOfs((size_t)d->n_textures, 0);
         for (int i = 0; i < d->n_textures; i++) {
             const mipt_texture& t = d->textures[i];
-            if (!t.rgb || t.width <= 0 || t.height <= 0) { delete s; return fail(MIPT_ERR_INVALID, "empty texture"); }
+            if (!t.rgb || t.width <= 0 || t.height <= 0) { return fail(MIPT_ERR_INVALID, "empty texture"); }
             texOfs[i] = (int)s->texels.size();
             s->texels.insert(s->texels.end(), t.rgb, t.rgb + (size_t)3 * t.width * t.height);
         }
@@ -514,7 +551,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         for (int i = 0; i < d->n_materials; i++) {
             const mipt_material& m = d->materials[i];
             if (m.type == MIPT_MAT_METAL || m.type == MIPT_MAT_GLASS) s->hasSpecular = true;
-            if (m.tex_id >= d->n_textures) { delete s; return fail(MIPT_ERR_INVALID, "material tex_id out of range"); }
+            if (m.tex_id >= d->n_textures) { return fail(MIPT_ERR_INVALID, "material tex_id out of range"); }
             const int ofs = m.tex_id >= 0 ? texOfs[m.tex_id] : -1;
             const int tw = m.tex_id >= 0 ? d->textures[m.tex_id].width : 0;
             const int th = m.tex_id >= 0 ? d->textures[m.tex_id].height : 0;
@@ -525,7 +562,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         }
         s->triAttr.assign((size_t)ptd::kTriAttrF4 * d->n_tris, make_float4(0, 0, 0, 0));
         for (int t = 0; t < d->n_tris; t++) {
-            if (d->mat_id[t] < 0 || d->mat_id[t] >= d->n_materials) { delete s; return fail(MIPT_ERR_INVALID, "mat_id out of range"); }
+            if (d->mat_id[t] < 0 || d->mat_id[t] >= d->n_materials) { return fail(MIPT_ERR_INVALID, "mat_id out of range"); }
             float f[28];
             memcpy(f, d->pos + (size_t)9 * t, 36);
             memcpy(f + 9, d->nrm + (size_t)9 * t, 36);
@@ -544,11 +581,9 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         }
         s->nNodes = n; s->nLeafTris = d->n_tri_index; s->nTris = d->n_tris; s->nMaterials = d->n_materials;
         s->envW = d->env_width; s->envH = d->env_height; s->nLights = d->n_lights;
-        *out = s;
+        *out = owner.release();
         return MIPT_OK;
-    } catch (const std::bad_alloc&) {
-        return fail(MIPT_ERR_NOMEM, "out of host memory");
-    }
+    });
 }
 
 void mipt_scene_destroy(mipt_scene* s) { delete s; }
@@ -556,6 +591,7 @@ int mipt_scene_exact_reciprocal(const mipt_scene* s) { return (s && s->planesTam
 int mipt_scene_wide_nodes(const mipt_scene* s) { return (s && s->wideOk) ? s->nWide : 0; }
 
 int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx** out) {
+    return guarded("mipt_context_create", [&]() -> int {
     if (!s || !out) return fail(MIPT_ERR_INVALID, "mipt_context_create: null argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MIPT_ERR_DEVICE, "no HIP device available");
@@ -565,7 +601,9 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
         const int rcs = resolve_scratch(device);  // the no-alloc entry point's buffer on this GPU
         if (rcs != MIPT_OK) return rcs;
     }
-    mipt_ctx* c = new mipt_ctx();
+    struct CtxDeleter { void operator()(mipt_ctx* p) const { mipt_context_destroy(p); } };
+    std::unique_ptr<mipt_ctx, CtxDeleter> owner(new mipt_ctx());  // destroyed on every failure path, exceptions included
+    mipt_ctx* c = owner.get();
     c->device = device;
     c->scratch = (unsigned char*)g_scratchPtr[device];
     if (const char* tv = getenv("MIPT_TRAVERSAL")) {  // A/B runs without touching the caller: walk | bittrail
@@ -574,7 +612,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     }
     if (stream) c->stream = (hipStream_t)stream;
     else {
-        if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(MIPT_ERR_DEVICE, "hipStreamCreate failed"); }
+        if (hipStreamCreate(&c->stream) != hipSuccess) return fail(MIPT_ERR_DEVICE, "hipStreamCreate failed");
         c->ownStream = true;
     }
     // one arena, 256-B aligned sections
@@ -605,10 +643,9 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t oLeafHead = o; if (!s->leafHead.empty()) memcpy(&stage[o], s->leafHead.data(), s->leafHead.size() * sizeof(float4)); o += szLeafHead;
     const size_t oRight = o; if (!s->nodeRight.empty()) memcpy(&stage[o], s->nodeRight.data(), s->nodeRight.size() * sizeof(int)); o += szRight;
     const size_t oBt = o; if (!s->btLinks.empty()) memcpy(&stage[o], s->btLinks.data(), s->btLinks.size() * sizeof(int4));
-    if (hipMalloc(&c->arena, total) != hipSuccess) { mipt_context_destroy(c); return fail(MIPT_ERR_DEVICE, "hipMalloc(arena) failed"); }
+    if (hipMalloc(&c->arena, total) != hipSuccess) return fail(MIPT_ERR_DEVICE, "hipMalloc(arena) failed");
     c->arenaBytes = total;
     if (hipMemcpy(c->arena, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
-        mipt_context_destroy(c);
         return fail(MIPT_ERR_DEVICE, "arena upload failed");
     }
     unsigned char* base = (unsigned char*)c->arena;
@@ -635,11 +672,11 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.nWideTop = s->nWide < ptd::kWideTopNodes ? s->nWide : ptd::kWideTopNodes;
     if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->dTotals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
-        mipt_context_destroy(c);
         return fail(MIPT_ERR_DEVICE, "hipMalloc(stats) failed");
     }
-    *out = c;
+    *out = owner.release();
     return MIPT_OK;
+    });
 }
 
 void mipt_context_destroy(mipt_ctx* c) {
@@ -740,13 +777,14 @@ int mipt_context_set_traversal(mipt_ctx* c, int traversal) {
     if (traversal == MIPT_TRAVERSAL_THREADED) { c->useBitTrail = false; c->useWide = false; return MIPT_OK; }
     if (traversal == MIPT_TRAVERSAL_BITTRAIL) {
         if (!c->ds.btOk)
-            return fail(MIPT_ERR_LIMIT, "bit-trail traversal needs a proper binary tree of depth <= 31 (the reference's 32-bit trail)");
+            return fail(MIPT_ERR_LIMIT, "bit-trail traversal needs a proper binary tree (two children per interior node, one parent each) of depth <= 31, the width of the reference's 32-bit trail");
         c->useBitTrail = true;
         return MIPT_OK;
     }
     return fail(MIPT_ERR_INVALID, "unknown traversal");
 }
 int mipt_context_get_stats(mipt_ctx* c, mipt_stats* out) {
+    return guarded("mipt_context_get_stats", [&]() -> int {
     if (!c || !out) return fail(MIPT_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     int rc = drain_timers(c);
@@ -761,6 +799,7 @@ int mipt_context_get_stats(mipt_ctx* c, mipt_stats* out) {
     out->node_visits_occluded = h[4];
     out->tri_tests_occluded = h[5];
     return MIPT_OK;
+    });
 }
 int mipt_context_reset_stats(mipt_ctx* c) {
     if (!c) return fail(MIPT_ERR_INVALID, "null context");
@@ -833,6 +872,7 @@ int mipt_trace_device_noalloc(mipt_ctx* c, const void* rays_dev, size_t n, void*
 
 int mipt_trace(mipt_ctx* c, const float* ray_o, const float* ray_d, size_t n, float tmin, float tmax, int32_t* tri_id,
                float* t, float* bary, float* hitrec) {
+    return guarded("mipt_trace", [&]() -> int {
     if (!c || (n && (!ray_o || !ray_d))) return fail(MIPT_ERR_INVALID, "mipt_trace: null argument");
     if (n > 0x7fffffffu) return fail(MIPT_ERR_LIMIT, "mipt_trace: at most 2^31-1 rays per call");
     if (n == 0) return MIPT_OK;
@@ -869,10 +909,12 @@ int mipt_trace(mipt_ctx* c, const float* ray_o, const float* ray_d, size_t n, fl
         if (bary) { bary[2 * i] = hits[i].z; bary[2 * i + 1] = hits[i].w; }
     }
     return MIPT_OK;
+    });
 }
 
 int mipt_occluded(mipt_ctx* c, const float* ray_o, const float* ray_d, const float* tmin, const float* tmax, size_t n,
                   uint8_t* occluded) {
+    return guarded("mipt_occluded", [&]() -> int {
     if (!c || (n && (!ray_o || !ray_d || !tmin || !tmax || !occluded))) return fail(MIPT_ERR_INVALID, "mipt_occluded: null argument");
     if (n > 0x7fffffffu) return fail(MIPT_ERR_LIMIT, "mipt_occluded: at most 2^31-1 rays per call");
     if (n == 0) return MIPT_OK;
@@ -893,9 +935,11 @@ int mipt_occluded(mipt_ctx* c, const float* ray_o, const float* ray_d, const flo
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     return MIPT_OK;
+    });
 }
 
 int mipt_eye_rays(mipt_ctx* c, const mipt_camera* cam, size_t first, size_t count, float* ray_o, float* ray_d) {
+    return guarded("mipt_eye_rays", [&]() -> int {
     if (!c || !cam || (count && (!ray_o || !ray_d))) return fail(MIPT_ERR_INVALID, "mipt_eye_rays: null argument");
     CameraDev cd;
     int rc = make_camera(cam, cd);
@@ -919,6 +963,7 @@ int mipt_eye_rays(mipt_ctx* c, const mipt_camera* cam, size_t first, size_t coun
         ray_d[3 * i] = rays[2 * i + 1].x; ray_d[3 * i + 1] = rays[2 * i + 1].y; ray_d[3 * i + 2] = rays[2 * i + 1].z;
     }
     return MIPT_OK;
+    });
 }
 
 int mipt_background(mipt_ctx* c, const float* dir, size_t n, float* rgb) {
@@ -974,6 +1019,7 @@ static int ensure_path_buffers(mipt_ctx* c, size_t cap, size_t nPix) {
 }
 
 int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_params* rp, float* accum_dev, float* rgb_dev) {
+    return guarded("mipt_render_device", [&]() -> int {
     if (!c || !cam || !rp || !rgb_dev) return fail(MIPT_ERR_INVALID, "mipt_render_device: null argument");
     if (rp->mode < MIPT_MODE_PRIMARY || rp->mode > MIPT_MODE_PATH) return fail(MIPT_ERR_INVALID, "unknown render mode");
     if (rp->mode == MIPT_MODE_PATH && (!accum_dev || rp->spp <= 0 || rp->sample_offset < 0))
@@ -995,6 +1041,9 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
         for (int ty = 0; ty < tilesY; ty++)
             for (int tx = 0; tx < tilesX; tx++)
                 if ((tx + 3 * ty) % partCount == rp->part_index) tiles.push_back(ty * tilesX + tx);
+        // a frame still in flight on c->stream (which may be a non-blocking stream the null stream does not order
+        // against) reads the old list: let it finish before the list is replaced (rare: only when the key changes)
+        HIP_TRY(hipStreamSynchronize(c->stream));
         if ((rc = c->tileMem.ensure(tiles.size() * sizeof(int) + 4)) != MIPT_OK) return rc;
         if (!tiles.empty()) HIP_TRY(hipMemcpy(c->tileMem.p, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
         c->tileKey = key;
@@ -1092,6 +1141,7 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
     }
     HIP_TRY(hipGetLastError());
     return MIPT_OK;
+    });
 }
 
 int mipt_render(mipt_ctx* c, const mipt_camera* cam, const mipt_render_params* rp, float* rgb_host) {

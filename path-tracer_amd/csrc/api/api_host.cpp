@@ -1,6 +1,7 @@
 // api_host.cpp -- the host half of the C-ABI declared in include/mipt.h:
 // loaders, images, SAH-BVH build, scene description.  No GPU involved.
 #include <cstring>
+#include <memory>
 #include <new>
 
 #include "../pt/host.hpp"
@@ -222,21 +223,37 @@ const int32_t* mipt_bvh_id_sibling(const mipt_bvh* b) { return b ? b->bvh.idSibl
 const int32_t* mipt_bvh_tri_index(const mipt_bvh* b) { return b ? b->bvh.triIndex.data() : nullptr; }
 void mipt_bvh_destroy(mipt_bvh* b) { delete b; }
 
-int mipt_scene_cache_save(const char* path, const mipt_mesh* mesh, const mipt_bvh* bvh) {
+int mipt_scene_cache_save_tagged(const char* path, const mipt_mesh* mesh, const mipt_bvh* bvh, const char* tag) {
     if (!path || !mesh || !bvh) { pt::set_error("mipt_scene_cache_save: null argument"); return MIPT_ERR_INVALID; }
     MIPT_GUARD_BEGIN
-    return pt::saveSceneCache(path, mesh->mesh, bvh->bvh);
+    return pt::saveSceneCache(path, mesh->mesh, bvh->bvh, tag ? tag : "");
+    MIPT_GUARD_END
+}
+int mipt_scene_cache_save(const char* path, const mipt_mesh* mesh, const mipt_bvh* bvh) {
+    return mipt_scene_cache_save_tagged(path, mesh, bvh, "");
+}
+int mipt_scene_cache_load_tagged(const char* path, const char* expect_tag, mipt_mesh** mesh_out, mipt_bvh** bvh_out) {
+    if (!path || !mesh_out || !bvh_out) { pt::set_error("mipt_scene_cache_load: null argument"); return MIPT_ERR_INVALID; }
+    MIPT_GUARD_BEGIN
+    std::unique_ptr<mipt_mesh> m(new mipt_mesh());
+    std::unique_ptr<mipt_bvh> b(new mipt_bvh());
+    const std::string want = expect_tag ? expect_tag : "";
+    const int rc = pt::loadSceneCache(path, m->mesh, b->bvh, expect_tag ? &want : nullptr);
+    if (rc != MIPT_OK) return rc;
+    *mesh_out = m.release();
+    *bvh_out = b.release();
+    return MIPT_OK;
     MIPT_GUARD_END
 }
 int mipt_scene_cache_load(const char* path, mipt_mesh** mesh_out, mipt_bvh** bvh_out) {
-    if (!path || !mesh_out || !bvh_out) { pt::set_error("mipt_scene_cache_load: null argument"); return MIPT_ERR_INVALID; }
+    return mipt_scene_cache_load_tagged(path, nullptr, mesh_out, bvh_out);
+}
+/* "name:size:fnv1a64" of a file's content into out (NUL-terminated, truncated to out_size) */
+int mipt_file_fingerprint(const char* path, char* out, size_t out_size) {
+    if (!path || !out || out_size == 0) { pt::set_error("mipt_file_fingerprint: null argument"); return MIPT_ERR_INVALID; }
     MIPT_GUARD_BEGIN
-    mipt_mesh* m = new mipt_mesh();
-    mipt_bvh* b = new mipt_bvh();
-    const int rc = pt::loadSceneCache(path, m->mesh, b->bvh);
-    if (rc != MIPT_OK) { delete m; delete b; return rc; }
-    *mesh_out = m;
-    *bvh_out = b;
+    const std::string fp = pt::fileFingerprint(path);
+    snprintf(out, out_size, "%s", fp.c_str());
     return MIPT_OK;
     MIPT_GUARD_END
 }

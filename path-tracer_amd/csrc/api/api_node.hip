@@ -1,0 +1,417 @@
+// api_node.hip -- one frame over the GPUs of a node (north_star subsystem 4): mipt_node_* and
+// mipt_render_node of include/mipt.h.
+//
+// The reference renders a frame with one kernel launch and reads it back (gpu/src/cs488.h:3209-3216); here the frame
+// is cut into tiles, rank r (one host thread + one HIP stream + one mipt_ctx per GPU, the scene arena replicated)
+// renders the tiles with (tx + 3*ty) % N == r, and ONE collective per frame moves the owned tiles to rank 0:
+//     render -> k_pack_tiles (owned tiles -> dense send buffer) -> ncclGather to rank 0 -> k_unpack_tiles -> readback
+// RCCL over xGMI: rank 0 receives from its N-1 peers over N-1 distinct links (3.1 MB per rank for a 1080p frame on 8
+// GPUs); there is no all-reduce (a ring all-reduce of whole frames would move N times the bytes for nothing).  The
+// per-pixel counter RNG is keyed on the global pixel index, so the gathered frame is bit-identical to the one-GPU
+// frame.  RCCL is loaded with dlopen when the first node is made (a process that never makes one never loads it, and
+// a process that already holds a copy -- torch ships one -- shares it).  Ranks that share a GPU (device ids repeated
+// in mipt_node_create: rehearsal on a one-GPU machine) cannot form an RCCL communicator; their gather is N
+// device-to-device copies ordered by events, everything else is the same code.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../device/kernels.hpp"
+#include "../pt/host.hpp"
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+std::mutex g_rcclMutex;
+Rccl g_rccl;
+
+// nullptr (with g_rccl.error set) when the library or one of its symbols is missing
+const Rccl* load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rcclMutex);
+    if (g_rccl.handle) return &g_rccl;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) { g_rccl.error = std::string("RCCL not loadable: ") + dlerror(); return nullptr; }
+    Rccl r;
+    r.handle = h;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.Gather = (decltype(r.Gather))dlsym(h, "ncclGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.Gather || !r.GetErrorString) {
+        g_rccl.error = "RCCL lacks ncclCommInitAll / ncclCommDestroy / ncclGather / ncclGetErrorString";
+        dlclose(h);
+        return nullptr;
+    }
+    g_rccl = r;
+    return &g_rccl;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Rank {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mipt_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    hipEvent_t packed = nullptr;  // same-GPU gather: this rank's tiles have arrived in rank 0's receive buffer
+    // frame state, (re)allocated when the resolution or the tiling changes
+    void* frameMem = nullptr;     // accum | rgb | send | (rank 0) recv | tile lists
+    float *accum = nullptr, *rgb = nullptr, *send = nullptr, *recv = nullptr;
+    int* tiles = nullptr;         // this rank's owned tile ids; rank 0: every rank's list, rank r's at tileOfs[r]
+    unsigned nTiles = 0;
+    unsigned long long layoutSeen = 0;  // the node's layoutGen this rank's frame memory was laid out for
+    int rc = MIPT_OK;
+    std::string error;
+};
+
+enum Job { JOB_NONE, JOB_RENDER, JOB_QUIT };
+
+}  // namespace
+
+struct mipt_node {
+    int n = 0;
+    bool useRccl = false;
+    const Rccl* rccl = nullptr;
+    std::vector<Rank> ranks;
+    std::vector<std::thread> threads;
+    // frame layout (valid while key matches)
+    std::vector<int> key;
+    int tileW = 0, tileH = 0, tilesX = 0, tilesY = 0;
+    std::vector<std::vector<int>> owned;   // per rank
+    std::vector<size_t> tileOfs;           // start of rank r's list inside rank 0's tile array
+    size_t maxTiles = 0, slotFloats = 0;   // floats per rank in the gather (maxTiles x tile pixels x 3)
+    unsigned long long layoutGen = 0;      // bumped whenever the above changes
+    std::atomic<int> failed{0};            // a rank failed before the gather: nobody enters it
+    // job hand-over
+    std::mutex m;
+    std::condition_variable cvGo, cvDone;
+    unsigned long long generation = 0;
+    int job = JOB_NONE, pending = 0, arrived = 0;
+    unsigned long long arriveGen = 0;
+    mipt_camera cam{};
+    mipt_render_params rp{};
+    float* rgbHost = nullptr;
+    bool clear = false;
+    double lastMs = 0.0;
+};
+
+namespace {
+
+int fail(int code, const std::string& msg) {
+    pt::set_error(msg);
+    return code;
+}
+
+#define NODE_HIP(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            r.error = std::string(#expr) + " failed: " + hipGetErrorString(e_);             \
+            return MIPT_ERR_DEVICE;                                                         \
+        }                                                                                   \
+    } while (0)
+
+// all ranks meet here (host side) before rank 0 waits for their copies
+void rank_barrier(mipt_node* nd) {
+    std::unique_lock<std::mutex> lk(nd->m);
+    const unsigned long long gen = nd->arriveGen;
+    if (++nd->arrived == nd->n) {
+        nd->arrived = 0;
+        nd->arriveGen++;
+        nd->cvDone.notify_all();
+    } else {
+        nd->cvDone.wait(lk, [&] { return nd->arriveGen != gen; });
+    }
+}
+
+int ensure_frame(mipt_node* nd, int ri) {
+    Rank& r = nd->ranks[(size_t)ri];
+    const size_t frameBytes = align256((size_t)3 * nd->cam.width * nd->cam.height * sizeof(float));
+    const size_t sendBytes = align256(nd->slotFloats * sizeof(float));
+    const size_t recvBytes = ri == 0 ? align256(nd->slotFloats * sizeof(float) * (size_t)nd->n) : 0;
+    size_t nList = nd->owned[(size_t)ri].size();
+    if (ri == 0) { nList = 0; for (const auto& o : nd->owned) nList += o.size(); }
+    const size_t listBytes = align256(nList * sizeof(int) + 4);
+    if (r.frameMem) { NODE_HIP(hipStreamSynchronize(r.stream)); NODE_HIP(hipFree(r.frameMem)); r.frameMem = nullptr; }
+    NODE_HIP(hipMalloc(&r.frameMem, 2 * frameBytes + sendBytes + recvBytes + listBytes));
+    unsigned char* b = (unsigned char*)r.frameMem;
+    r.accum = (float*)b; r.rgb = (float*)(b + frameBytes); r.send = (float*)(b + 2 * frameBytes);
+    r.recv = ri == 0 ? (float*)(b + 2 * frameBytes + sendBytes) : nullptr;
+    r.tiles = (int*)(b + 2 * frameBytes + sendBytes + recvBytes);
+    std::vector<int> list;
+    if (ri == 0) for (const auto& o : nd->owned) list.insert(list.end(), o.begin(), o.end());
+    else list = nd->owned[(size_t)ri];
+    if (!list.empty()) NODE_HIP(hipMemcpy(r.tiles, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice));
+    NODE_HIP(hipMemsetAsync(r.frameMem, 0, 2 * frameBytes + sendBytes + recvBytes, r.stream));
+    r.nTiles = (unsigned)nd->owned[(size_t)ri].size();
+    return MIPT_OK;
+}
+
+// phase A: everything up to and including this rank's packed tiles, enqueued on its stream
+int render_rank_enqueue(mipt_node* nd, int ri) {
+    Rank& r = nd->ranks[(size_t)ri];
+    NODE_HIP(hipSetDevice(r.device));
+    if (r.layoutSeen != nd->layoutGen || !r.frameMem) {
+        const int rc = ensure_frame(nd, ri);
+        if (rc != MIPT_OK) return rc;
+        r.layoutSeen = nd->layoutGen;
+    } else if (nd->clear) {
+        const size_t frameBytes = align256((size_t)3 * nd->cam.width * nd->cam.height * sizeof(float));
+        NODE_HIP(hipMemsetAsync(r.frameMem, 0, 2 * frameBytes, r.stream));  // AccumulationBuffer.clear(), sampleCount = 0
+    }
+    mipt_render_params rp = nd->rp;
+    rp.part_index = ri; rp.part_count = nd->n; rp.tile_w = nd->tileW; rp.tile_h = nd->tileH;
+    const int rc = mipt_render_device(r.ctx, &nd->cam, &rp, r.accum, r.rgb);
+    if (rc != MIPT_OK) { r.error = mipt_last_error(); return rc; }
+    if (nd->useRccl || (nd->n > 1 && ri != 0))  // rank 0's own tiles are already in its frame; ncclGather wants its share too
+        ptd::launch_pack_tiles(r.stream, r.rgb, ri == 0 ? r.tiles + nd->tileOfs[0] : r.tiles, r.nTiles, nd->tileW, nd->tileH,
+                               nd->tilesX, nd->cam.width, nd->cam.height, r.send);
+    NODE_HIP(hipGetLastError());
+    return MIPT_OK;
+}
+// phase B: the gather to rank 0, rank 0's unpack and readback.  Entered only when EVERY rank came through phase A (a
+// collective that one rank never joins would leave the others' streams waiting for ever).
+int render_rank_gather(mipt_node* nd, int ri) {
+    Rank& r = nd->ranks[(size_t)ri];
+    if (nd->n > 1 || nd->useRccl) {
+        if (nd->useRccl) {
+            const ncclResult_t e = nd->rccl->Gather(r.send, r.recv, nd->slotFloats, ncclFloat, 0, r.comm, r.stream);
+            if (e != ncclSuccess) { r.error = std::string("ncclGather failed: ") + nd->rccl->GetErrorString(e); return MIPT_ERR_DEVICE; }
+        } else {  // ranks share a GPU: a device-to-device copy into rank 0's slot, ordered by an event
+            hipError_t ce = hipSuccess;
+            if (ri != 0) {
+                ce = hipMemcpyAsync(nd->ranks[0].recv + (size_t)ri * nd->slotFloats, r.send, nd->slotFloats * sizeof(float),
+                                    hipMemcpyDeviceToDevice, r.stream);
+                if (ce == hipSuccess) ce = hipEventRecord(r.packed, r.stream);
+            }
+            rank_barrier(nd);  // every event is recorded (a rank that failed still comes here: nobody waits for ever)
+            NODE_HIP(ce);
+            if (ri == 0)
+                for (int k = 1; k < nd->n; k++) NODE_HIP(hipStreamWaitEvent(r.stream, nd->ranks[(size_t)k].packed, 0));
+        }
+        if (ri == 0)
+            for (int k = 1; k < nd->n; k++)
+                ptd::launch_unpack_tiles(r.stream, r.recv + (size_t)k * nd->slotFloats, r.tiles + nd->tileOfs[(size_t)k],
+                                         (unsigned)nd->owned[(size_t)k].size(), nd->tileW, nd->tileH, nd->tilesX, nd->cam.width,
+                                         nd->cam.height, r.rgb);
+        NODE_HIP(hipGetLastError());
+    }
+    if (ri == 0 && nd->rgbHost)
+        NODE_HIP(hipMemcpyAsync(nd->rgbHost, r.rgb, (size_t)3 * nd->cam.width * nd->cam.height * sizeof(float), hipMemcpyDeviceToHost, r.stream));
+    NODE_HIP(hipStreamSynchronize(r.stream));
+    return MIPT_OK;
+}
+int render_rank(mipt_node* nd, int ri) {
+    Rank& r = nd->ranks[(size_t)ri];
+    int rc = render_rank_enqueue(nd, ri);
+    if (rc != MIPT_OK) nd->failed.store(1);
+    rank_barrier(nd);  // every rank has enqueued its frame (or failed); same-GPU ranks have recorded their events
+    if (nd->failed.load()) {
+        (void)hipStreamSynchronize(r.stream);
+        if (rc == MIPT_OK) { rc = MIPT_ERR_DEVICE; r.error = "another rank failed before the gather"; }
+        return rc;
+    }
+    rc = render_rank_gather(nd, ri);
+    if (!nd->useRccl && nd->n > 1) rank_barrier(nd);  // rank 0 has consumed its receive buffer before anyone packs into it again
+    return rc;
+}
+
+void worker(mipt_node* nd, int ri) {
+    unsigned long long seen = 0;
+    for (;;) {
+        int job;
+        {
+            std::unique_lock<std::mutex> lk(nd->m);
+            nd->cvGo.wait(lk, [&] { return nd->generation != seen; });
+            seen = nd->generation;
+            job = nd->job;
+        }
+        if (job == JOB_QUIT) return;
+        Rank& r = nd->ranks[(size_t)ri];
+        r.error.clear();
+        const int rc = render_rank(nd, ri);
+        {
+            std::lock_guard<std::mutex> lk(nd->m);
+            r.rc = rc;
+            if (--nd->pending == 0) nd->cvDone.notify_all();
+        }
+    }
+}
+
+void run_job(mipt_node* nd, int job) {
+    std::unique_lock<std::mutex> lk(nd->m);
+    nd->job = job;
+    nd->pending = nd->n;
+    nd->generation++;
+    nd->cvGo.notify_all();
+    if (job != JOB_QUIT) nd->cvDone.wait(lk, [&] { return nd->pending == 0; });
+}
+
+}  // namespace
+
+extern "C" {
+
+int mipt_node_create(const mipt_scene* scene, int ngpus, const int* devices, mipt_node** out) {
+    if (!scene || !out || ngpus <= 0 || ngpus > 64) return fail(MIPT_ERR_INVALID, "mipt_node_create: bad argument (1..64 GPUs)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MIPT_ERR_DEVICE, "no HIP device available");
+    std::vector<int> devs((size_t)ngpus);
+    for (int i = 0; i < ngpus; i++) devs[(size_t)i] = devices ? devices[i] : i;
+    bool distinct = true;
+    for (int i = 0; i < ngpus; i++) {
+        if (devs[(size_t)i] < 0 || devs[(size_t)i] >= ndev)
+            return fail(MIPT_ERR_DEVICE, "mipt_node_create: device " + std::to_string(devs[(size_t)i]) + " of " + std::to_string(ndev) + " does not exist");
+        for (int k = 0; k < i; k++) distinct = distinct && devs[(size_t)k] != devs[(size_t)i];
+    }
+    mipt_node* nd = nullptr;
+    try {
+        nd = new mipt_node();
+        nd->n = ngpus;
+        nd->ranks.resize((size_t)ngpus);
+        for (int i = 0; i < ngpus; i++) {
+            Rank& r = nd->ranks[(size_t)i];
+            r.device = devs[(size_t)i];
+            if (hipSetDevice(r.device) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&r.packed, hipEventDisableTiming) != hipSuccess) {
+                mipt_node_destroy(nd);
+                return fail(MIPT_ERR_DEVICE, "mipt_node_create: stream / event creation failed on device " + std::to_string(r.device));
+            }
+            const int rc = mipt_context_create(scene, r.device, r.stream, &r.ctx);
+            if (rc != MIPT_OK) { mipt_node_destroy(nd); return rc; }
+        }
+        if (distinct) {  // one communicator over the node's GPUs (also for N = 1: the same code runs on every N)
+            nd->rccl = load_rccl();
+            if (!nd->rccl) { const std::string e = g_rccl.error; mipt_node_destroy(nd); return fail(MIPT_ERR_DEVICE, e); }
+            std::vector<ncclComm_t> comms((size_t)ngpus, nullptr);
+            const ncclResult_t e = nd->rccl->CommInitAll(comms.data(), ngpus, devs.data());
+            if (e != ncclSuccess) {
+                const std::string msg = std::string("ncclCommInitAll failed: ") + nd->rccl->GetErrorString(e);
+                mipt_node_destroy(nd);
+                return fail(MIPT_ERR_DEVICE, msg);
+            }
+            for (int i = 0; i < ngpus; i++) nd->ranks[(size_t)i].comm = comms[(size_t)i];
+            nd->useRccl = true;
+        }
+        for (int i = 0; i < ngpus; i++) nd->threads.emplace_back(worker, nd, i);
+    } catch (const std::exception& e) {
+        if (nd) mipt_node_destroy(nd);
+        return fail(MIPT_ERR_NOMEM, std::string("mipt_node_create: ") + e.what());
+    }
+    *out = nd;
+    return MIPT_OK;
+}
+
+void mipt_node_destroy(mipt_node* nd) {
+    if (!nd) return;
+    if (!nd->threads.empty()) {
+        run_job(nd, JOB_QUIT);
+        for (auto& t : nd->threads) t.join();
+    }
+    for (Rank& r : nd->ranks) {
+        (void)hipSetDevice(r.device);
+        if (r.stream) (void)hipStreamSynchronize(r.stream);
+        if (r.comm && nd->rccl) (void)nd->rccl->CommDestroy(r.comm);
+        if (r.ctx) mipt_context_destroy(r.ctx);
+        if (r.frameMem) (void)hipFree(r.frameMem);
+        if (r.packed) (void)hipEventDestroy(r.packed);
+        if (r.stream) (void)hipStreamDestroy(r.stream);
+    }
+    delete nd;
+}
+
+int mipt_node_num_gpus(const mipt_node* nd) { return nd ? nd->n : 0; }
+int mipt_node_uses_rccl(const mipt_node* nd) { return (nd && nd->useRccl) ? 1 : 0; }
+
+int mipt_node_render(mipt_node* nd, const mipt_camera* cam, const mipt_render_params* rp, float* rgb_host) {
+    if (!nd || !cam || !rp) return fail(MIPT_ERR_INVALID, "mipt_node_render: null argument");
+    if (cam->width <= 0 || cam->height <= 0 || cam->width > 32768 || cam->height > 32768)
+        return fail(MIPT_ERR_INVALID, "camera: bad resolution");
+    const int tileW = rp->tile_w > 0 ? rp->tile_w : 64, tileH = rp->tile_h > 0 ? rp->tile_h : 8;
+    if ((tileW & 7) || (tileH & 7)) return fail(MIPT_ERR_INVALID, "tile_w and tile_h must be multiples of 8");
+    try {
+        const std::vector<int> key = {cam->width, cam->height, tileW, tileH};
+        const bool relayout = key != nd->key;
+        if (relayout) {
+            nd->tileW = tileW; nd->tileH = tileH;
+            nd->tilesX = (cam->width + tileW - 1) / tileW; nd->tilesY = (cam->height + tileH - 1) / tileH;
+            nd->owned.assign((size_t)nd->n, {});
+            for (int ty = 0; ty < nd->tilesY; ty++)
+                for (int tx = 0; tx < nd->tilesX; tx++) nd->owned[(size_t)((tx + 3 * ty) % nd->n)].push_back(ty * nd->tilesX + tx);  // as mipt_render_device
+            nd->tileOfs.assign((size_t)nd->n, 0);
+            nd->maxTiles = 0;
+            size_t o = 0;
+            for (int r = 0; r < nd->n; r++) { nd->tileOfs[(size_t)r] = o; o += nd->owned[(size_t)r].size(); nd->maxTiles = std::max(nd->maxTiles, nd->owned[(size_t)r].size()); }
+            nd->slotFloats = nd->maxTiles * (size_t)tileW * tileH * 3;
+            nd->key = key;
+            nd->layoutGen++;  // the workers lay their frame memory out again
+        }
+        nd->cam = *cam; nd->rp = *rp; nd->rgbHost = rgb_host;
+        nd->failed.store(0);
+        nd->clear = !(rp->mode == MIPT_MODE_PATH && rp->sample_offset > 0);  // a progressive call continues its accumulation
+        const auto t0 = std::chrono::steady_clock::now();
+        run_job(nd, JOB_RENDER);
+        nd->lastMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } catch (const std::exception& e) {
+        return fail(MIPT_ERR_NOMEM, std::string("mipt_node_render: ") + e.what());
+    }
+    for (int i = 0; i < nd->n; i++)
+        if (nd->ranks[(size_t)i].rc != MIPT_OK) {
+            const int rc = nd->ranks[(size_t)i].rc;
+            nd->key.clear();  // whatever state the ranks are in, the next call lays the frame out again
+            return fail(rc, "rank " + std::to_string(i) + " (device " + std::to_string(nd->ranks[(size_t)i].device) + "): " + nd->ranks[(size_t)i].error);
+        }
+    return MIPT_OK;
+}
+
+int mipt_node_get_stats(mipt_node* nd, mipt_stats* out, double* last_frame_ms) {
+    if (!nd || !out) return fail(MIPT_ERR_INVALID, "mipt_node_get_stats: null argument");
+    mipt_stats sum{};
+    for (Rank& r : nd->ranks) {
+        mipt_stats s{};
+        const int rc = mipt_context_get_stats(r.ctx, &s);
+        if (rc != MIPT_OK) return rc;
+        sum.rays_closest += s.rays_closest; sum.rays_occluded += s.rays_occluded;
+        sum.launches_closest += s.launches_closest; sum.launches_occluded += s.launches_occluded; sum.launches_other += s.launches_other;
+        sum.ms_closest += s.ms_closest; sum.ms_occluded += s.ms_occluded; sum.ms_other += s.ms_other;
+        sum.node_visits_closest += s.node_visits_closest; sum.tri_tests_closest += s.tri_tests_closest;
+        sum.node_visits_occluded += s.node_visits_occluded; sum.tri_tests_occluded += s.tri_tests_occluded;
+    }
+    *out = sum;
+    if (last_frame_ms) *last_frame_ms = nd->lastMs;
+    return MIPT_OK;
+}
+
+int mipt_render_node(const mipt_scene* scene, const mipt_camera* cam, const mipt_render_params* params, int ngpus,
+                     float* rgb_out_rank0) {
+    if (!rgb_out_rank0) return fail(MIPT_ERR_INVALID, "mipt_render_node: null output");
+    mipt_node* nd = nullptr;
+    int rc = mipt_node_create(scene, ngpus, nullptr, &nd);
+    if (rc != MIPT_OK) return rc;
+    rc = mipt_node_render(nd, cam, params, rgb_out_rank0);
+    const std::string err = rc != MIPT_OK ? mipt_last_error() : "";
+    mipt_node_destroy(nd);
+    if (rc != MIPT_OK) pt::set_error(err);
+    return rc;
+}
+
+}  // extern "C"

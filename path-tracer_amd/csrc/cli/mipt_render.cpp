@@ -8,6 +8,8 @@
 //               [--eye x y z] [--lookat x y z] [--light x y z w] [--device 0]
 //               [--out image.png] [--out-hdr image.hdr] [--out-pfm image.pfm]
 //               [--traversal default|walk|bittrail] [--bvh reference|all-axes]
+//               [--gpus N]               the frame's tiles over GPUs 0..N-1, gathered to GPU 0 with one RCCL collective
+//                                        (mipt_node_*); the image is bit-identical to the one-GPU image
 //               [--cache scene.miptsc]   mesh + BVH from this flat file when it exists and loads, else parsed and
 //                                        built as usual and then written to it (mipt_scene_cache_*)
 #include <chrono>
@@ -35,7 +37,7 @@ int main(int argc, char** argv) {
     rp.mode = MIPT_MODE_DIRECT;  // the reference's default frame is Raytrace(), cs488.h:2620
     rp.spp = 1; rp.max_bounces = 4; rp.seed = 1; rp.part_count = 1;
     mipt_light light{{3.0f, 3.0f, 3.0f}, {1000.0f, 1000.0f, 1000.0f}};  // main.cpp:26-27
-    int device = 0, traversal = MIPT_TRAVERSAL_DEFAULT;
+    int device = 0, traversal = MIPT_TRAVERSAL_DEFAULT, gpus = 0;
     bool allAxes = false;
     for (int i = 1; i < argc; i++) {
         auto need = [&](int k) { if (i + k >= argc) { fprintf(stderr, "missing value after %s\n", argv[i]); exit(2); } };
@@ -48,6 +50,7 @@ int main(int argc, char** argv) {
         else if (a == "--bounces") { need(1); rp.max_bounces = atoi(argv[++i]); }
         else if (a == "--seed") { need(1); rp.seed = (uint32_t)strtoul(argv[++i], nullptr, 10); }
         else if (a == "--device") { need(1); device = atoi(argv[++i]); }
+        else if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
         else if (a == "--out") { need(1); outPng = argv[++i]; }
         else if (a == "--out-hdr") { need(1); outHdr = argv[++i]; }
         else if (a == "--out-pfm") { need(1); outPfm = argv[++i]; }
@@ -73,7 +76,20 @@ int main(int argc, char** argv) {
     mipt_mesh* mesh = nullptr;
     mipt_bvh* bvh = nullptr;
     auto t0 = std::chrono::high_resolution_clock::now();
-    const bool cached = !cachePath.empty() && mipt_scene_cache_load(cachePath.c_str(), &mesh, &bvh) == MIPT_OK;
+    // what a cache must have been built from to stand in for this run: the .obj (and the .mtl beside it) by size and
+    // content hash, and the BVH mode.  A cache with another tag is rebuilt and overwritten, not rendered.
+    std::string tag;
+    if (!cachePath.empty()) {
+        char fp[512];
+        mipt_file_fingerprint(scenePath.c_str(), fp, sizeof fp);
+        tag = std::string("obj ") + fp;
+        const size_t dot = scenePath.rfind('.');
+        const std::string mtl = (dot == std::string::npos ? scenePath : scenePath.substr(0, dot)) + ".mtl";
+        mipt_file_fingerprint(mtl.c_str(), fp, sizeof fp);
+        tag += std::string("; mtl ") + fp + "; bvh " + (allAxes ? "all-axes" : "reference");
+    }
+    const bool cached = !cachePath.empty() && mipt_scene_cache_load_tagged(cachePath.c_str(), tag.c_str(), &mesh, &bvh) == MIPT_OK;
+    if (!cachePath.empty() && !cached) printf("Cache not used: %s\n", mipt_last_error());
     if (cached) {
         printf("Loaded cache \"%s\" with %d triangles (%.1f ms).\n", cachePath.c_str(), mipt_mesh_num_triangles(mesh),
                std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count());
@@ -94,30 +110,46 @@ int main(int argc, char** argv) {
         auto t1 = std::chrono::high_resolution_clock::now();
         printf("Built BVH: %d nodes, %d leaves, depth %d (%.1f ms)\n", mipt_bvh_num_nodes(bvh), mipt_bvh_num_leaves(bvh),
                mipt_bvh_depth(bvh), std::chrono::duration<double, std::milli>(t1 - t0).count());
-        if (!cachePath.empty() && mipt_scene_cache_save(cachePath.c_str(), mesh, bvh) != MIPT_OK)
+        if (!cachePath.empty() && mipt_scene_cache_save_tagged(cachePath.c_str(), mesh, bvh, tag.c_str()) != MIPT_OK)
             fprintf(stderr, "mipt_render: cache not written: %s\n", mipt_last_error());
     }
     mipt_scene_desc desc;
     if (mipt_scene_desc_fill(mesh, bvh, env, &light, 1, &desc) != MIPT_OK) die("scene description");
     mipt_scene* scene = nullptr;
     if (mipt_scene_create(&desc, &scene) != MIPT_OK) die("scene");
-    mipt_ctx* ctx = nullptr;
-    if (mipt_context_create(scene, device, nullptr, &ctx) != MIPT_OK) die("context");
-    printf("Arena: %zu bytes on device %d\n", mipt_context_arena_bytes(ctx), device);
-    if (mipt_context_set_traversal(ctx, traversal) != MIPT_OK) die("traversal");
+    if (cam.width <= 0 || cam.height <= 0 || cam.width > 32768 || cam.height > 32768) {
+        fprintf(stderr, "mipt_render: --width / --height must be in 1..32768\n");
+        return 2;
+    }
     std::vector<float> rgb((size_t)3 * cam.width * cam.height);
-    auto t2 = std::chrono::high_resolution_clock::now();
-    if (mipt_render(ctx, &cam, &rp, rgb.data()) != MIPT_OK) die("render");
-    auto t3 = std::chrono::high_resolution_clock::now();
+    mipt_ctx* ctx = nullptr;
+    mipt_node* node = nullptr;
     mipt_stats st;
-    mipt_context_get_stats(ctx, &st);
-    const double ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    double ms;
+    if (gpus > 0) {
+        if (traversal != MIPT_TRAVERSAL_DEFAULT) { fprintf(stderr, "mipt_render: --gpus renders with the default traversal\n"); return 2; }
+        if (mipt_node_create(scene, gpus, nullptr, &node) != MIPT_OK) die("node");
+        printf("Node: %d GPU(s), gather over %s\n", mipt_node_num_gpus(node), mipt_node_uses_rccl(node) ? "RCCL" : "device copies");
+        auto t2 = std::chrono::high_resolution_clock::now();
+        if (mipt_node_render(node, &cam, &rp, rgb.data()) != MIPT_OK) die("render");
+        ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t2).count();
+        if (mipt_node_get_stats(node, &st, nullptr) != MIPT_OK) die("stats");
+    } else {
+        if (mipt_context_create(scene, device, nullptr, &ctx) != MIPT_OK) die("context");
+        printf("Arena: %zu bytes on device %d\n", mipt_context_arena_bytes(ctx), device);
+        if (mipt_context_set_traversal(ctx, traversal) != MIPT_OK) die("traversal");
+        auto t2 = std::chrono::high_resolution_clock::now();
+        if (mipt_render(ctx, &cam, &rp, rgb.data()) != MIPT_OK) die("render");
+        ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t2).count();
+        if (mipt_context_get_stats(ctx, &st) != MIPT_OK) die("stats");
+    }
     printf("Frame duration %.2f ms, %llu rays (%.1f Mrays/s)\n", ms,
            (unsigned long long)(st.rays_closest + st.rays_occluded), (st.rays_closest + st.rays_occluded) / ms * 1e-3);
     if (!outPng.empty() && mipt_image_save_png(outPng.c_str(), cam.width, cam.height, rgb.data()) != MIPT_OK) die("save png");
     if (!outHdr.empty() && mipt_image_save_hdr(outHdr.c_str(), cam.width, cam.height, rgb.data()) != MIPT_OK) die("save hdr");
     if (!outPfm.empty() && mipt_image_save_pfm(outPfm.c_str(), cam.width, cam.height, rgb.data()) != MIPT_OK) die("save pfm");
-    mipt_context_destroy(ctx);
+    if (node) mipt_node_destroy(node);
+    if (ctx) mipt_context_destroy(ctx);
     mipt_scene_destroy(scene);
     mipt_bvh_destroy(bvh);
     if (env) mipt_image_destroy(env);

@@ -214,6 +214,16 @@ int decodeHDR(const char* fileName, std::vector<float>& rgb, int& w, int& h) {
         set_error("unsupported HDR data layout");
         return MIPT_ERR_IO;
     }
+    // the header's dimensions against what the file can hold, before anything is allocated: an RLE scanline takes at
+    // least 4 bytes of header plus 2 bytes per run of up to 127 pixels and channel
+    {
+        const size_t left = f.size() > p ? f.size() - p : 0;
+        const size_t minRow = ww >= 8 && ww < 32768 ? 4 + 8 * (((size_t)ww + 126) / 127) : (size_t)4 * ww;
+        if (ww > 32768 || hh > 32768 || (size_t)hh * (minRow < (size_t)4 * ww ? minRow : (size_t)4 * ww) > left) {
+            set_error("HDR header announces more pixels than the file holds");
+            return MIPT_ERR_IO;
+        }
+    }
     w = ww;
     h = hh;
     rgb.assign((size_t)3 * ww * hh, 0.0f);

@@ -1,7 +1,9 @@
 // scene_cache.cpp -- flat binary cache of a loaded mesh and its built BVH (parsing bunny.obj and
 // the O(n log n) SAH sweep dominate start-up; the cache makes benchmark runs start at once).  One file:
-//   "MIPTSC01", u32 endianness probe, u32 record sizes, u64 FNV-1a of everything after the header, then
-//   counted sections of plain arrays in the order written below.  Host byte order, no pointers.
+//   "MIPTSC02", u32 endianness probe, u32 record sizes, u64 FNV-1a of everything after the header, then the
+//   source tag (a string the writer chose to identify what the cache was built from: the CLI stores the .obj /
+//   .mtl sizes and content hash and the BVH mode; a reader that passes a tag gets MIPT_ERR_IO for a cache with
+//   another one) and counted sections of plain arrays in the order written below.  Host byte order, no pointers.
 // Loading checks the magic, the probe, the record sizes, the checksum and every count against the file size;
 // the arrays' CONTENT is validated where it is used (mipt_scene_create checks every link and index).
 #include <cstdio>
@@ -12,7 +14,7 @@
 namespace pt {
 namespace {
 
-constexpr char kMagic[8] = {'M', 'I', 'P', 'T', 'S', 'C', '0', '1'};
+constexpr char kMagic[8] = {'M', 'I', 'P', 'T', 'S', 'C', '0', '2'};  // 02: the payload starts with the source tag
 constexpr uint32_t kProbe = 0x01020304u;
 
 struct Writer {
@@ -59,8 +61,9 @@ uint64_t fnv1a64(const uint8_t* p, size_t n) {
 
 }  // namespace
 
-int saveSceneCache(const char* path, const TriangleMesh& m, const StacklessBVH& b) {
+int saveSceneCache(const char* path, const TriangleMesh& m, const StacklessBVH& b, const std::string& tag) {
     Writer w;
+    w.str(tag);
     w.vec(m.positions); w.vec(m.normals); w.vec(m.texcoords); w.vec(m.idMaterial);
     w.u64(m.materials.size());
     for (const Material& mt : m.materials) {
@@ -87,7 +90,7 @@ int saveSceneCache(const char* path, const TriangleMesh& m, const StacklessBVH& 
     return MIPT_OK;
 }
 
-int loadSceneCache(const char* path, TriangleMesh& m, StacklessBVH& b) {
+int loadSceneCache(const char* path, TriangleMesh& m, StacklessBVH& b, const std::string* expectTag) {
     FILE* f = fopen(path, "rb");
     if (!f) { set_error(std::string("cannot open ") + path); return MIPT_ERR_IO; }
     std::vector<uint8_t> all;
@@ -103,6 +106,9 @@ int loadSceneCache(const char* path, TriangleMesh& m, StacklessBVH& b) {
     if (probe != kProbe || sizes[0] != sizeof(float) || sizes[1] != sizeof(int32_t)) { set_error(std::string(path) + ": written on an incompatible machine"); return MIPT_ERR_IO; }
     if (fnv1a64(all.data() + header, all.size() - header) != sum) { set_error(std::string(path) + ": checksum mismatch"); return MIPT_ERR_IO; }
     Reader r{all.data() + header, all.data() + all.size()};
+    std::string tag;
+    if (!r.str(tag)) { set_error(std::string(path) + ": truncated"); return MIPT_ERR_IO; }
+    if (expectTag && tag != *expectTag) { set_error(std::string(path) + ": built from another source (cache tag '" + tag + "', wanted '" + *expectTag + "')"); return MIPT_ERR_IO; }
     r.vec(m.positions); r.vec(m.normals); r.vec(m.texcoords); r.vec(m.idMaterial);
     const uint64_t nMat = r.u64();
     if (!r.ok || nMat > all.size()) { set_error(std::string(path) + ": truncated"); return MIPT_ERR_IO; }
@@ -134,6 +140,25 @@ int loadSceneCache(const char* path, TriangleMesh& m, StacklessBVH& b) {
     if (!shape) { set_error(std::string(path) + ": inconsistent array sizes"); return MIPT_ERR_IO; }
     m.refreshCViews();
     return MIPT_OK;
+}
+
+// size and FNV-1a of a file's content as "name:size:hash"; "name:absent" when it cannot be read
+std::string fileFingerprint(const char* path) {
+    const char* base = strrchr(path, '/');
+    std::string out = base ? base + 1 : path;
+    FILE* f = fopen(path, "rb");
+    if (!f) return out + ":absent";
+    uint64_t h = 1469598103934665603ull, n = 0;
+    uint8_t chunk[1 << 16];
+    size_t got;
+    while ((got = fread(chunk, 1, sizeof chunk, f)) > 0) {
+        for (size_t i = 0; i < got; i++) { h ^= chunk[i]; h *= 1099511628211ull; }
+        n += got;
+    }
+    fclose(f);
+    char buf[64];
+    snprintf(buf, sizeof buf, ":%llu:%016llx", (unsigned long long)n, (unsigned long long)h);
+    return out + buf;
 }
 
 }  // namespace pt

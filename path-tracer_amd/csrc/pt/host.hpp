@@ -86,7 +86,9 @@ public:
 };
 
 // flat binary cache of a loaded mesh + built BVH (host/scene_cache.cpp)
-int saveSceneCache(const char* path, const TriangleMesh& mesh, const StacklessBVH& bvh);
-int loadSceneCache(const char* path, TriangleMesh& mesh, StacklessBVH& bvh);
+// tag: what the cache was built from (free text); a load with expectTag != nullptr refuses a cache with another tag
+int saveSceneCache(const char* path, const TriangleMesh& mesh, const StacklessBVH& bvh, const std::string& tag = std::string());
+int loadSceneCache(const char* path, TriangleMesh& mesh, StacklessBVH& bvh, const std::string* expectTag = nullptr);
+std::string fileFingerprint(const char* path);  // "name:size:fnv1a64" of a file's content
 
 }  // namespace pt

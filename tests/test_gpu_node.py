@@ -1,0 +1,80 @@
+"""mipt_node_* / mipt_render_node (include/mipt.h): one frame over the GPUs of a node, through the C-ABI.
+On the one-GPU test box: a 1-GPU node exercises the real RCCL path (communicator, ncclGather, pack / unpack kernels);
+nodes whose ranks share GPU 0 exercise N > 1 (thread per rank, tile ownership, the gather's layout, unpack on rank 0)
+with device-to-device copies in place of RCCL.  Bar: the node's frame equals the one-context frame bit for bit (the
+per-pixel counter RNG is keyed on the global pixel index)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def setup(B, sf):
+    arrays = sf.load_scene_arrays("cornellbox-glass")
+    scene = sf.product_scene_from_mesh_arrays(*arrays, env=sf.procedural_env(64))
+    ctx = B.Context(scene, device=0)
+    cam = B.default_camera(200, 150)  # neither a multiple of the 64 x 8 tile: edge tiles are clipped
+    ref_path = ctx.render(cam, mode=B.MODE_PATH, spp=5, max_bounces=4, seed=3)
+    ref_direct = ctx.render(cam, mode=B.MODE_DIRECT)
+    return scene, ctx, cam, ref_path, ref_direct
+
+
+def test_one_gpu_node_uses_rccl_and_equals_mipt_render(B, setup):
+    scene, ctx, cam, ref_path, ref_direct = setup
+    node = B.Node(scene, ngpus=1)
+    assert node.num_gpus == 1 and node.uses_rccl
+    img = node.render(cam, mode=B.MODE_PATH, spp=5, max_bounces=4, seed=3)
+    assert np.array_equal(bits(img), bits(ref_path))
+    assert np.array_equal(bits(node.render(cam, mode=B.MODE_DIRECT)), bits(ref_direct))
+    # progressive across calls: 2 + 3 samples == 5 samples; a call at sample 0 starts a new frame
+    node.render(cam, mode=B.MODE_PATH, spp=2, sample_offset=0, max_bounces=4, seed=3)
+    img = node.render(cam, mode=B.MODE_PATH, spp=3, sample_offset=2, max_bounces=4, seed=3)
+    assert np.array_equal(bits(img), bits(ref_path))
+    # another resolution and tiling on the same node: the frame memory is laid out again
+    cam2 = B.default_camera(96, 64)
+    assert np.array_equal(bits(node.render(cam2, mode=B.MODE_DIRECT, tile_w=16, tile_h=16)), bits(ctx.render(cam2, mode=B.MODE_DIRECT)))
+    assert node.render(cam, mode=B.MODE_DIRECT, readback=False) is None
+    st = node.stats()
+    assert st["rays_closest"] > 0 and st["last_frame_ms"] > 0
+    # the convenience entry point of SURVEY 8(b)
+    img = B.render_node(scene, cam, 1, mode=B.MODE_PATH, spp=5, max_bounces=4, seed=3)
+    assert np.array_equal(bits(img), bits(ref_path))
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_ranks_sharing_a_gpu_assemble_the_one_gpu_frame(B, setup, n):
+    scene, ctx, cam, ref_path, ref_direct = setup
+    node = B.Node(scene, devices=[0] * n)
+    assert node.num_gpus == n and not node.uses_rccl
+    for _ in range(2):  # twice: the send / receive buffers are reused
+        img = node.render(cam, mode=B.MODE_PATH, spp=5, max_bounces=4, seed=3)
+        assert np.array_equal(bits(img), bits(ref_path)), f"{n} ranks: {(bits(img) != bits(ref_path)).any(axis=2).sum()} pixels differ"
+    assert np.array_equal(bits(node.render(cam, mode=B.MODE_DIRECT)), bits(ref_direct))
+    # the ranks together traced exactly the rays of the one-context frame
+    ctx.reset_stats()
+    ctx.render(cam, mode=B.MODE_DIRECT)
+    one = ctx.stats()
+    before = node.stats()
+    node.render(cam, mode=B.MODE_DIRECT)
+    after = node.stats()
+    assert after["rays_closest"] - before["rays_closest"] == one["rays_closest"]
+    assert after["rays_occluded"] - before["rays_occluded"] == one["rays_occluded"]
+
+
+def test_node_errors(B, setup):
+    scene, ctx, cam, _, _ = setup
+    with pytest.raises(B.MiptError, match="does not exist"):
+        B.Node(scene, devices=[0, 99])
+    with pytest.raises(B.MiptError):
+        B.Node(scene, ngpus=0)
+    node = B.Node(scene, devices=[0, 0])
+    with pytest.raises(B.MiptError, match="multiples of 8"):
+        node.render(cam, mode=B.MODE_DIRECT, tile_w=12, tile_h=8)
+    with pytest.raises(B.MiptError):   # every rank refuses the same bad mode before the gather: no rank is left waiting
+        node.render(cam, mode=7)
+    assert np.array_equal(bits(node.render(cam, mode=B.MODE_DIRECT)), bits(setup[4]))  # and the node still works

@@ -166,6 +166,11 @@ def test_scene_outside_reciprocal_preconditions_takes_ieee_path(B, ob, sf):
         assert (b[0] >= 0).sum() > 1000, variant
         assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and \
             np.array_equal(bits(a[2]), bits(b[2])), variant
+        # the bit-trail kernel divides the IEEE way and needs a binary tree, not tame planes
+        ctx.set_traversal(B.TRAVERSAL_BITTRAIL)
+        c = ctx.trace(o, d)
+        bb = orc.intersect(o, d, variant=ob.BITTRAIL)
+        assert np.array_equal(c[0], bb[0]) and np.array_equal(bits(c[1]), bits(bb[1])), variant
 
 
 @pytest.mark.parametrize("n", [1 << 13, 1 << 16])
@@ -296,12 +301,16 @@ def test_bittrail_kernel_is_the_references_scene_traversal(B, ob, sf, name):
 
 @pytest.mark.parametrize("name", ["cornellbox", "teapot-glass", "sponza-standin-trace"])
 def test_all_axes_bvh_gives_the_same_hits(B, ob, sf, name):
-    """the three-axis SAH tree (mipt_bvh_build_all_axes) against the reference's tree on the same rays: same
-    triangles, same t, bit for bit, except where a triangle's own leaf box decides (floating-point edge cases) or an
-    exact tie in t is broken by another visit order -- at most a few rays in 100,000; and fewer box tests"""
+    """the three-axis SAH tree (mipt_bvh_build_all_axes) against the ORACLE on the same rays (not
+    against another product context).  The oracle walks the reference's tree; its brute-force variant
+    (bruteforceIntersect, cs488.h:931-947) tests every triangle and knows no tree at all.  Same t bit for bit as the
+    threaded oracle except where a triangle's own leaf box decides (the reference's walk only tests a triangle whose
+    leaf box passes AABB::intersect; another tree has other leaf boxes) -- at most 1 ray in 10,000, and every such ray
+    must then agree with brute force or with the threaded walk; ids may differ on exact ties only; fewer box tests"""
     arrays = sf.sponza_standin(1) if name == "sponza-standin-trace" else sf.load_scene_arrays(name)
     ref_ctx = B.Context(sf.product_scene_from_mesh_arrays(*arrays), device=0)
     alt_ctx = B.Context(sf.product_scene_from_mesh_arrays(*arrays, all_axes=True), device=0)
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays)
     cam = B.default_camera(320, 240)
     o, d = ref_ctx.eye_rays(cam)
     rng = np.random.default_rng(21)
@@ -318,10 +327,19 @@ def test_all_axes_bvh_gives_the_same_hits(B, ob, sf, name):
         res.append(ctx.trace(o, d))
         counts.append(ctx.stats()["node_visits_closest"])
         ctx.set_counting(False)
-    a, b = res
-    same_t = bits(a[1]) == bits(b[1])
+    threaded = orc.intersect(o, d)
+    b = res[1]
+    assert np.array_equal(res[0][0], threaded[0]) and np.array_equal(bits(res[0][1]), bits(threaded[1]))  # the reference's tree: exact
+    same_t = bits(b[1]) == bits(threaded[1])
     assert (~same_t).sum() <= 1e-4 * len(o), (~same_t).sum()
-    assert ((a[0] != b[0]) & same_t).sum() <= 1e-3 * len(o)  # exact ties only
-    assert (a[0] >= 0).sum() > 0.2 * len(o)
+    assert ((b[0] != threaded[0]) & same_t).sum() <= 1e-3 * len(o)  # exact ties only
+    assert (b[0] >= 0).sum() > 0.2 * len(o)
+    odd = np.flatnonzero(~same_t)
+    if odd.size:  # the few rays a leaf box decides: brute force (no boxes at all) is the tie-breaker
+        brute = orc.intersect(o[odd], d[odd], variant=ob.BRUTEFORCE)
+        assert np.all((bits(b[1][odd]) == bits(brute[1])) | (bits(threaded[1][odd]) == bits(brute[1])))
+    sub = rng.choice(len(o), 3000, replace=False)  # and on a subsample the all-axes tree agrees with brute force outright
+    brute = orc.intersect(o[sub], d[sub], variant=ob.BRUTEFORCE)
+    assert (bits(b[1][sub]) != bits(brute[1])).sum() <= 2
     if name != "cornellbox":  # 36 triangles leave nothing to gain
         assert counts[1] < counts[0], counts

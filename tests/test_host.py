@@ -335,3 +335,36 @@ def test_all_axes_bvh_is_a_valid_tree_and_cheaper(B, sf):
     assert alt.depth <= 31 and alt.num_nodes < ref.num_nodes
     scene = B.Scene(mesh, bvh=alt, lights=sf.SPONZA_LIGHT)
     assert scene.wide_nodes > 0 and scene.exact_reciprocal
+
+
+def test_scene_cache_source_tag(B, tmp_path):
+    """a cache records what it was built from; a load that names another source is refused (the CLI then
+    rebuilds), a load without a tag takes any cache"""
+    mesh = B.Mesh.single_triangle()
+    bvh = B.BVH(mesh)
+    path = str(tmp_path / "tagged.miptsc")
+    src = tmp_path / "a.obj"
+    src.write_text("v 0 0 0\n")
+    tag = "obj " + B.file_fingerprint(str(src)) + "; bvh reference"
+    assert B.file_fingerprint(str(src)).startswith("a.obj:8:") and B.file_fingerprint(str(tmp_path / "none.obj")) == "none.obj:absent"
+    B.save_scene_cache(path, mesh, bvh, tag=tag)
+    B.load_scene_cache(path, expect_tag=tag)
+    B.load_scene_cache(path)
+    src.write_text("v 0 0 1\n")  # same size, other content
+    tag2 = "obj " + B.file_fingerprint(str(src)) + "; bvh reference"
+    assert tag2 != tag
+    with pytest.raises(B.MiptError, match="another source"):
+        B.load_scene_cache(path, expect_tag=tag2)
+    with pytest.raises(B.MiptError, match="another source"):
+        B.load_scene_cache(path, expect_tag=tag.replace("reference", "all-axes"))
+
+
+def test_hdr_header_larger_than_file_is_refused(B, tmp_path):
+    """an .hdr whose header announces more pixels than the file can hold must fail before allocating"""
+    p = tmp_path / "huge.hdr"
+    p.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 30000 +X 30000\n" + bytes(64))
+    with pytest.raises(B.MiptError, match="more pixels"):
+        B.Image.load(str(p))
+    p.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2000000000 +X 2000000000\n" + bytes(64))
+    with pytest.raises(B.MiptError):
+        B.Image.load(str(p))

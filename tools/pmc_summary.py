@@ -54,15 +54,29 @@ for k, d in out.items():
         if c in d:
             print(f"    {c}: {d[c]:.4g}")
 if "--traffic" in sys.argv:
-    t = {}
+    sys.path.insert(0, root)
+    import bench  # kernel_source_hash(): bench.py reports these counters only for the sources they were recorded for
+    t = {"kernel_source_hash": bench.kernel_source_hash(), "recorded_as": f"profiles/{rnd}/pmc_{tag}.json"}
     for k in ("k_trace_closest", "k_trace_occluded", "k_trace_wide_closest", "k_trace_wide_occluded"):
         if k in out and "hbm_read_bytes_per_launch" in out[k]:
             t[k] = {"hbm_bytes_per_launch": out[k]["hbm_read_bytes_per_launch"] + out[k].get("hbm_write_bytes_per_launch", 0.0),
                     "source": f"profiles/{rnd}/pmc_{tag}.json: 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes of "
                               "bench.py --steps 2 --warmup 1, averaged over that kernel's launches"}
-            if out[k].get("SQ_ACTIVE_INST_VALU") and out[k].get("GRBM_GUI_ACTIVE"):
-                # vector-ALU issue: quad-cycles in which a wavefront issued a VALU instruction, per SIMD (1024 on the
-                # chip), over the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
-                t[k]["valu_active_frac"] = (out[k]["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (out[k]["GRBM_GUI_ACTIVE"] / 8.0)
-                t[k]["l2_hit_rate"] = out[k].get("l2_hit_rate")
+            t[k]["l2_hit_rate"] = out[k].get("l2_hit_rate")
+            if out[k].get("SQ_INSTS_VALU") and out[k].get("GRBM_GUI_ACTIVE"):
+                # Vector-ALU issue-slot occupancy.  SQ_ACTIVE_INST_VALU ticks once per VALU instruction on this part
+                # whatever the instruction costs (profiles/README.md, "unit of SQ_ACTIVE_INST_VALU"), so it is not a
+                # busy time; instead: instructions x issue cost per class (tools/micro/issue_rate.hip: fp32 add / mul /
+                # fma 2 cycles per wave64 instruction, everything else -- min/max/cmp/cndmask/packed/int/mov with
+                # SGPR operands -- 4) over SIMDs x kernel cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024
+                # SIMDs on the chip).
+                o = out[k]
+                cheap = sum(o.get(c, 0.0) for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
+                have_mix = any(c in o for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
+                cyc = (2.0 * cheap + 4.0 * (o["SQ_INSTS_VALU"] - cheap)) if have_mix else 4.0 * o["SQ_INSTS_VALU"]
+                t[k]["valu_issue_occupancy"] = (cyc / 1024.0) / (o["GRBM_GUI_ACTIVE"] / 8.0)
+                t[k]["valu_issue_occupancy_basis"] = "measured class mix" if have_mix else "upper bound: every instruction at 4 cycles"
+                if o.get("lanes_per_valu_inst"):
+                    t[k]["lanes_per_valu_inst"] = o["lanes_per_valu_inst"]
+                    t[k]["useful_lane_frac"] = t[k]["valu_issue_occupancy"] * o["lanes_per_valu_inst"] / 64.0
     json.dump(t, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
