@@ -245,9 +245,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_loop(spp_per_step):
+    def timed_loop(spp_per_step, profile=False):
         """W warm-up steps, then exactly K timed steps of spp_per_step samples of the frame (this rank's tiles), each
-        followed by the gather; -> (seconds, stats of the timed steps, index of the first timed sample)"""
+        followed by the gather; -> (seconds, stats of the timed steps, index of the first timed sample).
+        profile: HIP events around every kernel launch, kernels serialised on one stream (the per-kernel pass)"""
         state = {"sample": 0}
 
         def step():
@@ -257,11 +258,12 @@ def main():
             gatherer.gather(rgb)  # no-op on one GPU
 
         accum.zero_()
+        ctx.set_overlap(not profile)
         for _ in range(args.warmup):
             step()
         sync()
         ctx.reset_stats()
-        ctx.set_profiling(True)  # HIP events around every kernel launch, on the stream the kernels run on
+        ctx.set_profiling(profile)  # on the stream the kernels run on
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -270,6 +272,7 @@ def main():
         elapsed = time.perf_counter() - t0
         st = ctx.stats()
         ctx.set_profiling(False)
+        ctx.set_overlap(True)
         return elapsed, st, state["sample"] - args.steps * spp_per_step
 
     def reduce_over_ranks(elapsed, st):
@@ -282,8 +285,13 @@ def main():
 
     # headline: one args.spp-sample frame per step, divided over the ranks (strong scaling; N = 1: the whole frame)
     spp_per_step = args.spp
-    elapsed, st, first = timed_loop(spp_per_step)
-    elapsed_max, total_rays = reduce_over_ranks(elapsed, st)
+    elapsed, st0, first = timed_loop(spp_per_step)
+    elapsed_max, total_rays = reduce_over_ranks(elapsed, st0)
+    # per-kernel durations for the roofline: the same K steps once more (same frames: the sample index restarts), with
+    # HIP events around every launch and the shadow-ray launches serialised behind the closest-hit ones -- in the timed
+    # loop above they overlap on two streams, where a launch's begin-to-end time includes waiting for CUs
+    serial_elapsed, st, _ = timed_loop(spp_per_step, profile=True)
+    assert st["rays_closest"] == st0["rays_closest"] and st["rays_occluded"] == st0["rays_occluded"]
 
     # per-kernel visit counts of exactly the same frames (deterministic), outside the timed region
     accum2 = torch.zeros_like(accum)
@@ -356,6 +364,7 @@ def main():
                                    f"(uffizi_probe.hdr absent), {part}",
                        "bvh": args.bvh, "resolution": [W, H], "bounces": BOUNCES, "spp_per_step": spp_per_step, "seed": SEED,
                        "rays_per_step": total_rays / args.steps, "ms_per_frame_1spp": ms_frame,
+                       "ms_per_step_serialised_with_events": serial_elapsed / args.steps * 1e3,
                        "weak_scaling": weak},
             "roofline": {"bound": "valu", "achieved": dom["achieved_TFLOPs"], "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom["achieved_TFLOPs"] / FP32_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": dom_name,
@@ -367,10 +376,13 @@ def main():
                          "pmc_note": pmc_note,
                          "per_kernel": {"k_trace_closest": kc, "k_trace_occluded": ko, "kernel_names": list(names),
                                         "other_ms_total": st["ms_other"], "other_launches": int(st["launches_other"])},
-                         "note": "achieved = algorithmic flops per launch (SURVEY 8(d): 27 per box test + 95 per triangle "
+                         "note": "per-kernel durations come from a second pass over the same K steps (this rank) with HIP events "
+                                 "around every launch and the kernels serialised on one stream (config."
+                                 "ms_per_step_serialised_with_events); the timed loop overlaps shadow-ray and extension-ray "
+                                 "launches on two streams. achieved = algorithmic flops per launch (SURVEY 8(d): 27 per box test + 95 per triangle "
                                  "test; box tests = 4 per visit of a 4-wide node + the exact test of each candidate leaf, "
                                  "counted by the COUNT instantiation on the same frames) / average launch duration from "
-                                 "HIP events in the timed region (rank 0), against the fp32 vector peak: the traversal is "
+                                 "those HIP events, against the fp32 vector peak: the traversal is "
                                  "bound by vector-ALU issue, not by HBM. -ffp-contract=off (bit-exactness) forbids FMA "
                                  "in the tests, so at most half of that peak is reachable. algorithmic_GBs = SURVEY 8(d)'s "
                                  "byte formula (48 B/ray + 32 B/box test + 36 B/triangle test) / the same duration: those "

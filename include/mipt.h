@@ -370,6 +370,12 @@ enum { MIPT_TRAVERSAL_DEFAULT = 0, MIPT_TRAVERSAL_THREADED = 1, MIPT_TRAVERSAL_B
 int mipt_context_set_traversal(mipt_ctx* ctx, int traversal);
 
 int mipt_context_synchronize(mipt_ctx* ctx);
+/* Path mode runs the shadow rays of bounce k (any-hit) on a side stream of the context, beside the extension rays of
+ * bounce k+1 (closest hit): the two are independent once the vertices of bounce k are shaded, and the later kernel's
+ * blocks fill the CUs the earlier one's tail leaves idle.  On by default; 0 serialises them on the context's stream
+ * (per-kernel HIP-event and rocprof durations are only meaningful then).  Frames are bit-identical either way.
+ * MIPT_OVERLAP=0 in the environment sets the default off.  No counterpart in the reference. */
+int mipt_context_set_overlap(mipt_ctx* ctx, int enabled);
 /* profiling: HIP events around every kernel launch on the context's stream */
 int mipt_context_set_profiling(mipt_ctx* ctx, int enabled);
 /* counting: the traversal kernels also count node visits and triangle tests */

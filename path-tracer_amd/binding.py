@@ -83,7 +83,7 @@ SYMBOLS = [
     "mipt_trace", "mipt_trace_device", "mipt_trace_device_noalloc", "mipt_occluded", "mipt_eye_rays", "mipt_background",
     "mipt_selftest_fast_division", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
     "mipt_render_device", "mipt_render", "mipt_context_synchronize", "mipt_context_set_profiling",
-    "mipt_context_set_counting", "mipt_context_get_stats", "mipt_context_reset_stats", "mipt_context_set_traversal",
+    "mipt_context_set_counting", "mipt_context_set_overlap", "mipt_context_get_stats", "mipt_context_reset_stats", "mipt_context_set_traversal",
     "mipt_node_create", "mipt_node_destroy", "mipt_node_num_gpus", "mipt_node_uses_rccl", "mipt_node_render",
     "mipt_node_get_stats", "mipt_render_node",
 ]
@@ -175,6 +175,7 @@ def lib():
     L.mipt_buffer_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.mipt_context_set_profiling.argtypes = [vp, C.c_int]
     L.mipt_context_set_counting.argtypes = [vp, C.c_int]
+    L.mipt_context_set_overlap.argtypes = [vp, C.c_int]
     L.mipt_context_set_traversal.argtypes = [vp, C.c_int]
     L.mipt_context_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mipt_context_reset_stats.argtypes = [vp]
@@ -595,6 +596,10 @@ class Context:
         """TRAVERSAL_DEFAULT (order-free wide tree), TRAVERSAL_THREADED (literal idHit/idMiss walk) or
         TRAVERSAL_BITTRAIL (StacklessBVH2::intersect, literal)"""
         check(lib().mipt_context_set_traversal(self.h, int(traversal)))
+
+    def set_overlap(self, on):
+        """path mode: shadow rays of bounce k beside the extension rays of bounce k+1 on a side stream (default on)"""
+        check(lib().mipt_context_set_overlap(self.h, int(on)))
 
     def set_counting(self, on):
         check(lib().mipt_context_set_counting(self.h, int(on)))

@@ -281,7 +281,14 @@ struct mipt_ctx {
     DevScene ds{};
     // scratch of the host-pointer entry points
     DevBuf sRays, sHits, sOut, sAux, sAux2;
-    DevBuf slow;           // rays the wide kernel handed back (trace_closest / trace_occluded)
+    DevBuf slow;           // rays the wide kernel handed back (trace_closest)
+    DevBuf slowOcc;        // ... and those of trace_occluded, which may run beside a closest-hit launch on the side stream
+    // Path mode overlaps occluded(it) with closest(it+1): once shade(it) has run the two are independent, and on a
+    // second stream the blocks of the later kernel move onto CUs as the earlier one's drain, which fills the
+    // 0.1-0.2 ms tail of every traversal launch (MIPT_OVERLAP=0 in the environment turns it off for A/B runs).
+    hipStream_t side = nullptr;
+    bool overlap = true;
+    std::vector<hipEvent_t> evShaded, evOccluded;  // per bounce iteration, created on first use (no timing)
     unsigned char* scratch = nullptr;  // this GPU's copy of the file-scope `scratch` array (mipt_trace_device_noalloc)
     bool useWide = true;   // MIPT_TRAVERSAL=walk in the environment forces the literal walk (A/B runs)
     bool useBitTrail = false;  // mipt_context_set_traversal(MIPT_TRAVERSAL_BITTRAIL)
@@ -325,11 +332,12 @@ struct Timer {
     mipt_ctx* c;
     hipEvent_t a = nullptr, b = nullptr;
     int cls;
-    Timer(mipt_ctx* ctx, int klass) : c(ctx), cls(klass) {
+    hipStream_t st;
+    Timer(mipt_ctx* ctx, int klass, hipStream_t stream = nullptr) : c(ctx), cls(klass), st(stream ? stream : ctx->stream) {
         if (!c->profiling) return;
         a = take();
         b = take();
-        if (a && b) (void)hipEventRecord(a, c->stream);
+        if (a && b) (void)hipEventRecord(a, st);
     }
     hipEvent_t take() {
         if (!c->freeEvents.empty()) {
@@ -343,7 +351,7 @@ struct Timer {
     }
     ~Timer() {
         if (!c->profiling || !a || !b) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         c->timed.push_back(TimedLaunch{a, b, cls});
     }
 };
@@ -358,9 +366,9 @@ void count_launch(mipt_ctx* c, int cls) {
 // Scenes that qualify (DevScene::nWide) go through the wide kernel first; it hands back the rays it may not take
 // (direction components that are zero, denormal, non-finite ...) in c->slow, and the literal walk traces those.
 // c->slow: [0] count, [1] cursor of the second launch, [2..] queue slots.
-int ensure_slow(mipt_ctx* c, size_t capacity) {
-    int rc = c->slow.ensure((capacity + 2) * sizeof(int));
-    if (rc == MIPT_OK) (void)hipMemsetAsync(c->slow.p, 0, 8, c->stream);
+int ensure_slow(mipt_ctx* c, DevBuf& buf, size_t capacity, hipStream_t st) {
+    int rc = buf.ensure((capacity + 2) * sizeof(int));
+    if (rc == MIPT_OK) (void)hipMemsetAsync(buf.p, 0, 8, st);
     return rc;
 }
 void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, unsigned* cursor, float4* hits) {
@@ -373,7 +381,7 @@ void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView 
     unsigned long long* cnt = c->counting ? c->dTotals + 2 : nullptr;
     if (c->useBitTrail) {
         launch_trace_bittrail_closest(c->stream, c->ds, rays, index, q, hits, cnt);
-    } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
+    } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slow, q.space, c->stream) == MIPT_OK) {
         unsigned* sl = (unsigned*)c->slow.p;
         launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, sl, (int*)(sl + 2));
         launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, (const int*)(sl + 2), sl);  // short list: a wavefront per ray
@@ -382,23 +390,27 @@ void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView 
         launch_trace_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt);
     }
 }
-void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueView q, unsigned* cursor, unsigned char* occ) {
+// st: the context's stream, or its side stream (path mode's overlap); a DevBuf that grows frees its old memory, so
+// growing is only safe while nothing is in flight on either stream -- ensure_path_buffers sizes slowOcc up front
+void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueView q, unsigned* cursor, unsigned char* occ,
+                    hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     if (!cursor) {
         cursor = (unsigned*)(c->dTotals + 7);
-        (void)hipMemsetAsync(cursor, 0, 4, c->stream);
+        (void)hipMemsetAsync(cursor, 0, 4, st);
     }
-    Timer t(c, 1);
+    Timer t(c, 1, st);
     count_launch(c, 1);
     unsigned long long* cnt = c->counting ? c->dTotals + 4 : nullptr;
     if (c->useBitTrail) {
-        launch_trace_bittrail_occluded(c->stream, c->ds, rays, target, q, occ, cnt);
-    } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, q.space) == MIPT_OK) {
-        unsigned* sl = (unsigned*)c->slow.p;
-        launch_trace_wide_occluded(c->stream, c->ds, rays, target, q, cursor, occ, cnt, sl, (int*)(sl + 2));
-        launch_trace_slow_occluded(c->stream, c->ds, rays, target, occ, cnt, (const int*)(sl + 2), sl);
-        launch_trace_occluded(c->stream, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, sl + 1, occ, cnt, (const int*)(sl + 2), sl);
+        launch_trace_bittrail_occluded(st, c->ds, rays, target, q, occ, cnt);
+    } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slowOcc, q.space, st) == MIPT_OK) {
+        unsigned* sl = (unsigned*)c->slowOcc.p;
+        launch_trace_wide_occluded(st, c->ds, rays, target, q, cursor, occ, cnt, sl, (int*)(sl + 2));
+        launch_trace_slow_occluded(st, c->ds, rays, target, occ, cnt, (const int*)(sl + 2), sl);
+        launch_trace_occluded(st, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, sl + 1, occ, cnt, (const int*)(sl + 2), sl);
     } else {
-        launch_trace_occluded(c->stream, c->ds, rays, target, q, cursor, occ, cnt);
+        launch_trace_occluded(st, c->ds, rays, target, q, cursor, occ, cnt);
     }
 }
 QueueView dense(size_t n) { return QueueView{nullptr, 0u, (unsigned)n}; }
@@ -610,6 +622,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
         c->useWide = std::string(tv) != "walk";
         c->useBitTrail = std::string(tv) == "bittrail" && s->btOk;
     }
+    if (const char* ov = getenv("MIPT_OVERLAP")) c->overlap = std::string(ov) != "0";
     if (stream) c->stream = (hipStream_t)stream;
     else {
         if (hipStreamCreate(&c->stream) != hipSuccess) return fail(MIPT_ERR_DEVICE, "hipStreamCreate failed");
@@ -683,9 +696,12 @@ void mipt_context_destroy(mipt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    for (auto e : c->evShaded) (void)hipEventDestroy(e);
+    for (auto e : c->evOccluded) (void)hipEventDestroy(e);
     for (auto& t : c->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : c->freeEvents) (void)hipEventDestroy(e);
-    c->slow.release(); c->sRays.release(); c->sHits.release(); c->sOut.release(); c->sAux.release(); c->sAux2.release();
+    c->slow.release(); c->slowOcc.release(); c->sRays.release(); c->sHits.release(); c->sOut.release(); c->sAux.release(); c->sAux2.release();
     c->pathMem.release(); c->tileMem.release(); c->frameMem.release();
     if (c->dTotals) (void)hipFree(c->dTotals);
     if (c->arena) (void)hipFree(c->arena);
@@ -742,6 +758,12 @@ int mipt_buffer_download(mipt_ctx* c, void* host_ptr, const void* dev_ptr, size_
 int mipt_context_synchronize(mipt_ctx* c) {
     if (!c) return fail(MIPT_ERR_INVALID, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->side) HIP_TRY(hipStreamSynchronize(c->side));
+    return MIPT_OK;
+}
+int mipt_context_set_overlap(mipt_ctx* c, int enabled) {
+    if (!c) return fail(MIPT_ERR_INVALID, "null context");
+    c->overlap = enabled != 0;
     return MIPT_OK;
 }
 int mipt_context_set_profiling(mipt_ctx* c, int enabled) {
@@ -757,6 +779,7 @@ int mipt_context_set_counting(mipt_ctx* c, int enabled) {
 
 static int drain_timers(mipt_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->side) HIP_TRY(hipStreamSynchronize(c->side));
     for (auto& t : c->timed) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
@@ -986,6 +1009,19 @@ int mipt_background(mipt_ctx* c, const float* dir, size_t n, float* rgb) {
     return MIPT_OK;
 }
 
+// the side stream and one event pair per bounce iteration (created once; events carry no timing)
+static int ensure_side(mipt_ctx* c, int nIter) {
+    if (!c->side) HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    while ((int)c->evShaded.size() < nIter) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        c->evShaded.push_back(a);
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        c->evOccluded.push_back(b);
+    }
+    return MIPT_OK;
+}
+
 // carve the integrator's buffers out of one allocation
 // cap = path slots (pixel slots x samples in flight); nPix = pixel slots (the metal chain of direct mode is per pixel)
 static int ensure_path_buffers(mipt_ctx* c, size_t cap, size_t nPix) {
@@ -1002,8 +1038,13 @@ static int ensure_path_buffers(mipt_ctx* c, size_t cap, size_t nPix) {
     const size_t oRes = take(cap * f4);
     const size_t oQ0 = take(space * 4), oQ1 = take(space * 4), oQA = take(space * 4);
     const size_t oSh = take(2 * space * nl * f4), oShT = take(space * nl * 4), oCnt = take(kCounterWords * 4);
+    if (c->side) HIP_TRY(hipStreamSynchronize(c->side));  // nothing may be in flight while buffers are replaced
+    HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = c->pathMem.ensure(o);
     if (rc != MIPT_OK) { c->pb.capacity = 0; c->pbPixels = 0; return rc; }
+    if ((rc = c->slow.ensure((space + 2) * sizeof(int))) != MIPT_OK || (rc = c->slowOcc.ensure((space * nl + 2) * sizeof(int))) != MIPT_OK) {
+        c->pb.capacity = 0; c->pbPixels = 0; return rc;
+    }
     c->pbPixels = nPix;
     unsigned char* b = (unsigned char*)c->pathMem.p;
     PathBuffers& pb = c->pb;
@@ -1095,11 +1136,16 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
             launch_generate(c->stream, cd, fp, pb);
         }
         int itDone = 0;
+        const bool pathMode = rp->mode == MIPT_MODE_PATH;
+        // path mode: occluded(it) runs on the side stream beside closest(it+1) (both depend only on shade(it));
+        // shade(it+1) waits for both.  Everything the side stream does is waited for on c->stream before this call
+        // returns, so the caller's ordering on c->stream holds.
+        const bool overlap = pathMode && c->overlap && !c->useBitTrail && ensure_side(c, lastIter + 1) == MIPT_OK;
         for (int it = 0; it <= lastIter; it++) {
             trace_closest(c, pb.rays, pb.qExt[it & 1],
                           QueueView{pb.counters + counter_index(it, 0, 0), pb.regionSize, pb.space},
                           pb.counters + counter_index(it, 3, 0), pb.hit);
-            const bool pathMode = rp->mode == MIPT_MODE_PATH;
+            if (overlap && it > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->evOccluded[(size_t)it - 1], 0));  // shade(it) reads occ of bounce it-1
             {
                 Timer tm(c, 2);
                 count_launch(c, 2);
@@ -1107,10 +1153,17 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
                 else launch_shade_a(c->stream, c->ds, fp, pb, it);
             }
             if (rp->mode != MIPT_MODE_PRIMARY) {
+                hipStream_t occStream = c->stream;
+                if (overlap) {
+                    HIP_TRY(hipEventRecord(c->evShaded[(size_t)it], c->stream));
+                    HIP_TRY(hipStreamWaitEvent(c->side, c->evShaded[(size_t)it], 0));
+                    occStream = c->side;
+                }
                 trace_occluded(c, pb.shRays, pb.shTarget,
                                QueueView{pb.counters + counter_index(it, 2, 0), pb.regionSize * (unsigned)nl,
                                          pb.space * (unsigned)nl},
-                               pb.counters + counter_index(it, 4, 0), pb.occ);
+                               pb.counters + counter_index(it, 4, 0), pb.occ, occStream);
+                if (overlap) HIP_TRY(hipEventRecord(c->evOccluded[(size_t)it], c->side));
                 if (!pathMode) {
                     Timer tm(c, 2);
                     count_launch(c, 2);
@@ -1129,6 +1182,7 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
                 if (next == 0) break;
             }
         }
+        if (overlap && itDone > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->evOccluded[(size_t)itDone - 1], 0));
         if (rp->mode == MIPT_MODE_PATH) {
             Timer tm(c, 2);
             count_launch(c, 2);

@@ -263,3 +263,17 @@ def test_headless_cli_renders_and_reuses_its_cache(B, tmp_path):
     assert second.returncode == 0, second.stderr
     assert "Loaded cache" in second.stdout and "Built BVH" not in second.stdout
     assert np.array_equal(read_pfm(pfm).view(np.uint32), want.view(np.uint32))
+
+
+def test_overlapped_and_serialised_bounces_give_the_same_frame(B, ob, sf):
+    """mipt_context_set_overlap: the shadow rays of bounce k on a side stream beside the extension rays of bounce k+1
+    (default) against everything on one stream -- same bits, deep paths included (Russian roulette from bounce 6 on)"""
+    scene, ctx, orc = setup_scene(B, sf, "cornellbox-glass")
+    cam = B.default_camera(200, 150)
+    frames = []
+    for on in (True, False, True):
+        ctx.set_overlap(on)
+        frames.append(ctx.render(cam, mode=B.MODE_PATH, spp=6, max_bounces=12, seed=11))
+    ctx.set_overlap(True)
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))

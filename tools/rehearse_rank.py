@@ -9,6 +9,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--parts", type=int, default=8)
 ap.add_argument("--part", type=int, default=3)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--strong", action="store_true", help="16 samples per step whatever --parts (one rank's share of ONE 16-spp frame: "
+                                                     "bench.py's headline for N > 1) instead of 16 * parts (its weak figure)")
 a = ap.parse_args()
 import torch
 import scene_fixtures as sf
@@ -20,9 +22,9 @@ ctx = B.Context(scene, device=0, stream=torch.cuda.current_stream(dev).cuda_stre
 cam = B.make_camera(W, H, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
 accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
 rgb = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
-spp, sample = 16 * a.parts, 0
-for k in range(a.steps + 1):
-    if k == 1:
+spp, sample = (16 if a.strong else 16 * a.parts), 0
+for k in range(a.steps + 2):
+    if k == 2:
         torch.cuda.synchronize(); ctx.reset_stats(); t0 = time.perf_counter()
     ctx.render_device(cam, B.RenderParams(B.MODE_PATH, spp, sample, 4, 1, a.part, a.parts, 64, 8), accum.data_ptr(), rgb.data_ptr())
     sample += spp
