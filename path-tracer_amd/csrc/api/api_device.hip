@@ -672,6 +672,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.nNodes = s->nNodes; c->ds.nLeafTris = s->nLeafTris; c->ds.nTris = s->nTris; c->ds.nMaterials = s->nMaterials;
     c->ds.envW = s->envW; c->ds.envH = s->envH; c->ds.nLights = s->nLights;
     c->ds.planesTame = s->planesTame ? 1 : 0;
+    if (const char* hb = getenv("MIPT_HAND_BACK_ALL")) c->ds.handBackAll = std::string(hb) == "1" ? 1 : 0;  // tests: every ray through k_trace_slow / list-mode k_trace
     c->ds.nTopNodes = s->nTopNodes;
     c->ds.wnodes = (const float4*)(base + oWide);
     c->ds.leafBox = (const float4*)(base + oLeafBox);

@@ -170,6 +170,17 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     float tMin = 0.0f, tMax = 0.0f;
     int bestTri = -1, bestSeq = 0x7fffffff;
     float bestT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;
+    // Deferred admission.  A triangle counts only if its leaf's EXACT box passes the reference's predicate; that test
+    // (two loads, ~35 instructions) is needed by the one or two lanes of an iteration whose triangle was accepted,
+    // and run inside the iteration it executes for the whole wavefront nearly every time.  Instead an accepted
+    // triangle becomes the lane's UNVERIFIED best (uLeaf >= 0; best* already hold it) and the box tests of all such
+    // lanes run together, once at the end of a leaf phase.  While a lane holds an unverified best, later triangles
+    // are filtered against it: if it verifies, that is what the reference's strict '<' would have done; if it does
+    // not (the conservative slot test admitted a leaf the reference never opens: a ray within 2^-19 of a box face),
+    // the filtering may have dropped a triangle that should have won, so the ray is handed to the exact walk
+    // (slowList) and traced again from scratch -- rare, and the result is the reference's either way.  Any-hit rays
+    // stop at their first accepted triangle and wait for the verdict: pass = occluded, fail = carry on.
+    int uLeaf = -1;
     unsigned nv = 0, nt = 0;
     unsigned chunkBase = 0, chunkLeft = 0, chunkShard = 0;
     // Rays are handed out in chunks, one atomic on the launch's one cursor per chunk.  Atomics on one address
@@ -187,7 +198,11 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         if (ANYHIT) {                                                                      \
             if (bestTri >= 0) occ[target ? (unsigned)target[queueSlot] : queueSlot] = 1;   \
         } else {                                                                           \
-            hits[raySlot] = make_float4(i2f(bestTri), bestT, bestB, bestG);                \
+            /* the id of the winning triangle sits in its leafTris record; looking it up here, once per ray, */ \
+            /* keeps it out of the leaf loop's registers */                               \
+            int id = -1;                                                                   \
+            if (bestSeq != 0x7fffffff) id = f2i(s.leafTris[3 * (size_t)bestSeq].w);        \
+            hits[raySlot] = make_float4(i2f(id), bestT, bestB, bestG);                     \
         }                                                                                  \
         hasRay = false;                                                                    \
         w = -1;                                                                            \
@@ -195,6 +210,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         sp = 0;                                                                            \
         groups = 0;                                                                        \
         cur = -1;                                                                          \
+        uLeaf = -1;                                                                        \
     } while (0)
 
     while (true) {
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
                     ox = r0.x; oy = r0.y; oz = r0.z; tMin = r0.w;
                     dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
-                    if (fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz})) {
+                    if (!s.handBackAll && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz})) {
                         yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
                         ynx = (float2v)(yx * 0x1.ffffcp-1f); yny = (float2v)(yy * 0x1.ffffcp-1f); ynz = (float2v)(yz * 0x1.ffffcp-1f);
                         yfx = (float2v)(yx * 0x1.00002p0f); yfy = (float2v)(yy * 0x1.00002p0f); yfz = (float2v)(yz * 0x1.00002p0f);
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                 }
             }
         }
-        if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();  // walked everything, nothing parked
+        if (hasRay && w < 0 && groups == 0 && cur < 0 && uLeaf < 0) PT_FINISH();  // walked everything, nothing parked, nothing unverified
         // ---- leaves: open parked leaves with the exact box test, test their triangles ----
         const unsigned long long mCanVisit = __ballot(w >= 0 && groups < kWideGroups);
         unsigned long long mPend = __ballot(cur >= 0 || groups > 0);
@@ -339,11 +355,12 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                 // candidate leaf counts only if its exact box passes the reference's predicate; "box passes AND
                 // triangle accepted" is evaluated triangle first, so the box test (and the load of the box) is paid
                 // only by the few lanes whose triangle would change the result.
-                const bool opening = cur < 0 && groups > 0;
+                const bool waiting = ANYHIT && uLeaf >= 0;  // an any-hit ray with an accepted triangle waits for its verdict
+                const bool opening = !waiting && cur < 0 && groups > 0;
 #if PT_DIAG_UTIL == 2
-                if (COUNT) { nv += (cur >= 0 || opening) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; }
+                if (COUNT) { nv += ((cur >= 0 && !waiting) || opening) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; }
 #endif
-                if (cur >= 0 || opening) {
+                if ((cur >= 0 && !waiting) || opening) {
                     // leafHead and leafTris lie in one arena less than 4 GB apart (checked when the context is made):
                     // one uniform base, 32-bit offsets
                     unsigned triOfs;
@@ -370,34 +387,42 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                                         vec3{ox, oy, oz}, vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
                     // the reference keeps the FIRST of equal t's in depth-first order: smaller leafTris index wins
                     acc = acc && (ANYHIT || t < bestT || (t == bestT && cur < bestSeq));
-                    bool boxMissed = false;
-                    if (acc) {  // rare: now the leaf must prove that the reference would have opened it
-                        const __attribute__((address_space(1))) float4v* rec =
-                            (const __attribute__((address_space(1))) float4v*)s.leafBox + 2 * (size_t)curLeaf;
-#if !PT_DIAG_UTIL
-                        if (COUNT) nv++;
-#endif
-                        boxMissed = !slab_hit_fast(rec[0], rec[1], ox, oy, oz, dx, dy, dz, yx, yy, yz);  // the reference's predicate
-                        acc = !boxMissed;
+                    if (acc) {  // provisionally the best; its leaf's exact box is tested at the end of this leaf phase
+                        // a verified best that an unverified one replaces is lost if the latter fails: that ray is
+                        // re-traced (see above), so nothing needs to be kept
+                        if (ANYHIT) bestTri = f2i(q0.w);  // any hit: the flag "something accepted"; closest hit: see PT_FINISH
+                        bestSeq = cur; bestT = t; bestB = be; bestG = ga;
+                        uLeaf = curLeaf;
                     }
-                    if (acc) {
-                        bestTri = f2i(q0.w); bestSeq = cur; bestT = t; bestB = be; bestG = ga;
-                    }
-                    if (ANYHIT && acc) {
-                        PT_FINISH();  // isHit: any accepted triangle decides
-                    } else if (boxMissed || f2i(q1.w)) {
-                        cur = -1;  // last triangle of this leaf, or a leaf the reference never opens
-                    } else {
-                        ++cur;
-                    }
+                    if (f2i(q1.w)) cur = -1;  // last triangle of this leaf
+                    else ++cur;
                 }
-                if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();
-                mPend = __ballot(cur >= 0 || groups > 0);
+                mPend = __ballot((cur >= 0 || groups > 0) && !(ANYHIT && uLeaf >= 0));
 #if PT_TUNE_WIDE_GREEDY
             } while (mPend != 0ull && __popcll(mPend) >= __popcll(__ballot(w >= 0 && groups < kWideGroups)));
 #else
             } while (__popcll(mPend) >= (ANYHIT ? PT_TUNE_WIDE_KEEP_ANYHIT : PT_TUNE_WIDE_KEEP));
 #endif
+            // ---- the verdicts: exact box predicate of every lane that holds an unverified best ----
+            if (uLeaf >= 0) {
+                const __attribute__((address_space(1))) float4v* rec =
+                    (const __attribute__((address_space(1))) float4v*)s.leafBox + 2 * (size_t)uLeaf;
+#if !PT_DIAG_UTIL
+                if (COUNT) nv++;
+#endif
+                const bool pass = slab_hit_fast(rec[0], rec[1], ox, oy, oz, dx, dy, dz, yx, yy, yz);  // the reference's predicate
+                uLeaf = -1;
+                if (ANYHIT) {
+                    if (pass) PT_FINISH();  // isHit: any accepted triangle decides
+                    else bestTri = -1;      // that triangle does not count; the search goes on
+                } else if (!pass) {
+                    // the filtering since that candidate may have dropped the true winner: trace this ray again, exactly
+                    unsigned at = atomicAdd(slowCount, 1u);
+                    slowList[at] = (int)queueSlot;
+                    hasRay = false; w = -1; tos = 0; sp = 0; groups = 0; cur = -1;
+                }
+            }
+            if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();
         }
     }
 #undef PT_FINISH

@@ -343,3 +343,34 @@ def test_all_axes_bvh_gives_the_same_hits(B, ob, sf, name):
     assert (bits(b[1][sub]) != bits(brute[1])).sum() <= 2
     if name != "cornellbox":  # 36 triangles leave nothing to gain
         assert counts[1] < counts[0], counts
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "sponza-standin-trace"])
+def test_rays_through_vertices_and_the_exact_walk_kernels_on_ordinary_rays(B, ob, sf, name, monkeypatch):
+    """rays from edge midpoints towards mesh vertices: exact ties in t between the triangles that share the vertex (the
+    reference keeps the first in depth-first order, cs488.h:1674), and leaf boxes the exact predicate rejects although
+    one of their triangles accepts the ray -- the cases the order-free traversal's deferred admission must get right
+    (an unverified best whose leaf box fails sends the ray to the exact walk kernels).  Second half: with
+    MIPT_HAND_BACK_ALL=1 every ray takes those kernels (k_trace_slow for short lists, list-mode k_trace for long
+    ones), which since deferred admission also see rays with ordinary directions"""
+    arrays = sf.sponza_standin(1) if name == "sponza-standin-trace" else sf.load_scene_arrays(name)
+    scene = sf.product_scene_from_mesh_arrays(*arrays)
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+    tri = np.asarray(arrays[0], np.float32).reshape(-1, 3, 3)
+    rng = np.random.default_rng(5)
+    for n in (3000, 30000):
+        k, k2 = rng.integers(0, len(tri), n), rng.integers(0, len(tri), n)
+        o = ((tri[k, 0] + tri[k, 1]) * np.float32(0.5)).astype(np.float32)
+        d = tri[k2, 2] - o
+        d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+        ref = orc.intersect(o, d)
+        oref = orc.occluded(o, d, 1e-4, 2.0)
+        assert (ref[0] >= 0).mean() > 0.5
+        for hand_back in ("0", "1"):
+            monkeypatch.setenv("MIPT_HAND_BACK_ALL", hand_back)
+            ctx = B.Context(scene, device=0)
+            got = ctx.trace(o, d)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and \
+                np.array_equal(bits(got[2]), bits(ref[2])), (name, n, hand_back)
+            assert np.array_equal(ctx.occluded(o, d, 1e-4, 2.0), oref), (name, n, hand_back)
+        monkeypatch.delenv("MIPT_HAND_BACK_ALL")
