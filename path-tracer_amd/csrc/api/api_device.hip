@@ -84,6 +84,39 @@ struct mipt_scene {
     bool wideOk = false;
 };
 
+// float -> fp16 bits rounded towards -inf (up == false) or +inf (up == true); finite input.  Returns 0x7c00 / 0xfc00
+// (infinity) when the value lies beyond the fp16 range on the side the rounding goes to.
+static unsigned short half_towards(float f, bool up) {
+    unsigned b;
+    memcpy(&b, &f, 4);
+    const unsigned sign = b >> 31, mag = b & 0x7fffffffu;
+    const bool away = up != (sign != 0);  // the magnitude is rounded away from zero
+    const int e = (int)(mag >> 23) - 127;
+    const unsigned m = mag & 0x7fffffu;
+    unsigned h;
+    if (mag == 0) h = 0;
+    else if (e < -24) h = away ? 1u : 0u;  // below the smallest fp16 denormal, 2^-24
+    else if (e < -14) {                    // fp16 denormal: units of 2^-24
+        const unsigned full = m | 0x800000u;
+        const int shift = -(e + 1);        // e = -15 -> 14 ... e = -24 -> 23
+        const unsigned q = full >> shift, rem = full & ((1u << shift) - 1u);
+        h = q + ((rem && away) ? 1u : 0u);
+    } else if (e > 15) h = away ? 0x7c00u : 0x7bffu;
+    else {
+        h = ((unsigned)(e + 15) << 10) | (m >> 13);
+        if ((m & 0x1fffu) && away) h += 1u;  // a carry runs into the exponent as it should
+    }
+    return (unsigned short)((sign << 15) | h);
+}
+static float half_value(unsigned short h) {
+    const unsigned sign = h >> 15, e = (h >> 10) & 31u, m = h & 1023u;
+    float v;
+    if (e == 0) v = std::ldexp((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp((float)(m | 1024u), (int)e - 25);
+    return sign ? -v : v;
+}
+
 // Is the threaded tree a proper binary tree (every interior node's idHit = its left child, that child's idMiss = the
 // right child, both further on in preorder, every node but the root with exactly one parent)?  The bit-trail links
 // and k_trace_slow's right-child table need exactly this; the box planes play no part in it.
@@ -236,12 +269,29 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
             }
         }
         float4* rec = &s->wnodes[(size_t)ptd::kWideNodeStrideF4 * w];
+#if PT_WIDE_HALF
+        for (int a = 0; a < 3; a++) {  // row a: {lo of slots 0..3, hi of slots 0..3} as fp16, each rounded outwards
+            unsigned short h[8];
+            for (int k = 0; k < 4; k++) {
+                h[k] = half_towards(lo[a][k], false);
+                h[4 + k] = half_towards(hi[a][k], true);
+                // the slot test must never be tighter than the box: checked, not assumed (and no infinities)
+                if (!(half_value(h[k]) <= lo[a][k]) || !(half_value(h[4 + k]) >= hi[a][k]) || (h[k] & 0x7fffu) >= 0x7c00u ||
+                    (h[4 + k] & 0x7fffu) >= 0x7c00u)
+                    return false;  // a plane beyond the fp16 range: this scene takes the literal walk
+            }
+            memcpy(&rec[a], h, 16);
+        }
+        rec[3] = make_float4(__builtin_bit_cast(float, childBase), __builtin_bit_cast(float, leafBase),
+                             __builtin_bit_cast(float, interiorMask | (leafMask << 4)), 0.0f);
+#else
         for (int a = 0; a < 3; a++) {
             rec[2 * a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
             rec[2 * a + 1] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
         }
         rec[6] = make_float4(__builtin_bit_cast(float, childBase), __builtin_bit_cast(float, leafBase),
                              __builtin_bit_cast(float, interiorMask | (leafMask << 4)), 0.0f);
+#endif
     }
     if (nextChild != nw) return false;
     s->nWide = nw;

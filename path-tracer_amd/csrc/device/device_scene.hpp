@@ -10,7 +10,11 @@
 //             (threaded links of StacklessBVH, reference cs488.h:1637-1659; 0 = done)
 //             Device numbering: the root is 0, the kTopNodes nodes with the largest boxes (a connected
 //             top of the tree) come first, the rest follow in preorder; the links are renumbered to match.
-//   wnodes    "wide": 7 x float4 per 4-wide node (112 B) over the SAME leaves, for rays that qualify for the
+//   wnodes    (PT_WIDE_HALF, the default) 4 x 16 B per 4-wide node: rows x, y, z = 8 halves {lo of slots 0..3, hi of slots
+//             0..3}, fp16 rounded OUTWARDS (lo down, hi up: the slot test only has to be conservative), row 3 =
+//             {bits(childBase), bits(leafBase), bits(interiorMask | leafMask << 4), 0}; 64 B, never straddling a line.
+//             Scenes with a plane beyond the fp16 range take the literal walk.  With PT_WIDE_HALF=0:
+//             "wide": 7 x float4 per 4-wide node (112 B) over the SAME leaves, for rays that qualify for the
 //             order-free traversal (kernels_trace.hip: k_trace_wide); built on the host from the binary tree
 //             (api_device.hip: build_wide), numbered breadth-first:
 //               {min.x of slots 0..3} {max.x} {min.y} {max.y} {min.z} {max.z}
@@ -82,14 +86,22 @@ constexpr int kTraceBlock = PT_TUNE_BLOCK;  // k_trace: 16 wavefronts per block,
 #define PT_TUNE_GRID 512
 #endif
 constexpr int kTriAttrF4 = 8;       // float4 per triAttr record
+#ifndef PT_WIDE_HALF
+#define PT_WIDE_HALF 1  // wide nodes with fp16 planes rounded outwards (64 B, four 16-B rows); 0: fp32 planes (112 B, seven rows)
+#endif
+#if PT_WIDE_HALF
+constexpr int kWideNodeF4 = 4;        // 16-B rows per wide node: x, y, z planes as 8 halves {lo of slots 0..3, hi of slots 0..3}, meta
+constexpr int kWideNodeStrideF4 = 4;  // 64-B records, 64-B aligned: a node never straddles a cache line
+#else
 constexpr int kWideNodeF4 = 7;      // float4 per wide node (its stride in LDS)
 #ifndef PT_TUNE_WIDE_NODE_STRIDE
 #define PT_TUNE_WIDE_NODE_STRIDE 7
 #endif
+constexpr int kWideNodeStrideF4 = PT_TUNE_WIDE_NODE_STRIDE;  // ... and in the arena (8 = one 128-B line per node)
+#endif
 #ifndef PT_TUNE_LEAFHEAD_STRIDE
 #define PT_TUNE_LEAFHEAD_STRIDE 3
 #endif
-constexpr int kWideNodeStrideF4 = PT_TUNE_WIDE_NODE_STRIDE;  // ... and in the arena (8 = one 128-B line per node)
 constexpr int kLeafHeadStrideF4 = PT_TUNE_LEAFHEAD_STRIDE;   // float4 per leafHead record (4 = half a line each)
 constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's per-lane stack can hold (binary depth 32)
 #ifndef PT_TUNE_WIDE_BLOCK
@@ -99,9 +111,9 @@ constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's pe
 #define PT_TUNE_WIDE_PER_CU 1
 #endif
 // LDS of one k_trace_wide block (PT_TUNE_WIDE_PER_CU blocks share a CU's 160 KB): the per-lane stacks (kWideMaxDepth
-// words per lane), the shard prefix sums, and the first kWideTopNodes wide nodes (112 B each)
+// words per lane), the shard prefix sums, and the first kWideTopNodes wide nodes (16 * kWideNodeF4 bytes each)
 #ifndef PT_TUNE_WIDE_TOP
-#define PT_TUNE_WIDE_TOP ((163840 / PT_TUNE_WIDE_PER_CU - 320 - 4 * kWideMaxDepth * PT_TUNE_WIDE_BLOCK) / 112)
+#define PT_TUNE_WIDE_TOP ((163840 / PT_TUNE_WIDE_PER_CU - 320 - 4 * kWideMaxDepth * PT_TUNE_WIDE_BLOCK) / (16 * kWideNodeF4))
 #endif
 constexpr int kWideBlocksPerCU = PT_TUNE_WIDE_PER_CU;
 constexpr int kWideTopNodes = PT_TUNE_WIDE_TOP;

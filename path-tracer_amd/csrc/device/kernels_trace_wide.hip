@@ -54,6 +54,13 @@ namespace ptd {
 #ifndef PT_TUNE_WIDE_GREEDY
 #define PT_TUNE_WIDE_GREEDY 0
 #endif
+#if PT_WIDE_HALF
+#undef PT_TUNE_WIDE_FMA
+#define PT_TUNE_WIDE_FMA 1  // the fp16 layout implies the fma form
+#endif
+#ifndef PT_TUNE_WIDE_FMA
+#define PT_TUNE_WIDE_FMA 1             // slot test with one fma per plane (wide_hit_mask_fma); 0: subtract and multiply for every ray
+#endif
 #ifndef PT_TUNE_WIDE_REFILL_ANYHIT
 #define PT_TUNE_WIDE_REFILL_ANYHIT PT_TUNE_WIDE_REFILL
 #endif
@@ -105,6 +112,73 @@ __device__ __forceinline__ int wide_hit_mask(const float4v nearx, const float4v 
     const float u2 = fmaxf(fmaxf(fmaxf(nxb.x, nyb.x), nzb.x), 0.0f), v2 = fminf(fminf(fxb.x, fyb.x), fzb.x);
     const float u3 = fmaxf(fmaxf(fmaxf(nxb.y, nyb.y), nzb.y), 0.0f), v3 = fminf(fminf(fxb.y, fyb.y), fzb.y);
     return (!(u0 > v0) ? 1 : 0) | (!(u1 > v1) ? 2 : 0) | (!(u2 > v2) ? 4 : 0) | (!(u3 > v3) ? 8 : 0);
+}
+
+// The same test with ONE fused multiply-add per plane, t~ = fma(p, y', -c), instead of a subtraction and a product:
+// 24 v_fma_f32 per visit in place of 24 v_sub_f32 + 12 v_pk_mul_f32, about half the issue cycles of the arithmetic.
+// What is lost is the exact cancellation of p - o: the constant c = o y' is rounded, so a plane that coincides with
+// the ray's origin no longer gives exactly 0, and the slack has to be absolute.  With u = 2^-24, A = o y' (real),
+// c0 = RN(A), near: y' = yn = RN(y (1 - 2^-19)), cn = RN(c0 + 2^-22 |c0|)  ==>  cn - A in [1.5 u |A|, 7 u |A|], hence
+//     t~n = RN(p yn - cn) = RN((p - o) yn - D),  D in [1.5, 7] u |A|,   (p - o) yn = T r,  r < 1 - 2^-20,
+// where T = (p - o) / d is the real quotient and the reference's q = RN(RN(p - o) / d) lies within 2.0001 u |T| of it
+// with the same sign.  T > 0: t~n <= max(T r (1 + u), 0) <= T (1 - 2^-21) <= q.  T <= 0: T r - D <= 0, so t~n <= 0 and
+// the clamp at 0 makes its size irrelevant.  Far planes mirror this (yf = RN(y (1 + 2^-19)), cf = RN(c0f - 2^-22 |c0f|)):
+// T >= 0 gives t~f >= T (1 + 2^-21) >= q, and T < 0 is rejected by the reference whatever t~f is.  So the exact
+// predicate max(t1, 0) <= t2 implies max(t~1, 0) <= t~2: conservative, as the order-free traversal requires.
+// The price is a slack of up to 7 u |o| in SPACE along each axis, i.e. 7 u |o y| in t: harmless while |y| is moderate,
+// but a ray with a tiny direction component (huge y) that starts ON a box plane -- every secondary ray starts on a
+// wall -- would then pass every box that touches that plane within a long stretch of t.  Such rays (a direction
+// component below 2^-12, 7 in 10,000) keep the subtract-and-multiply form: `precise` lanes, same kernel.
+__device__ __forceinline__ int wide_hit_mask_fma(const float4v nearx, const float4v farx, const float4v neary, const float4v fary,
+                                                 const float4v nearz, const float4v farz, const float ynx, const float yny,
+                                                 const float ynz, const float yfx, const float yfy, const float yfz,
+                                                 const float cnx, const float cny, const float cnz, const float cfx,
+                                                 const float cfy, const float cfz) {
+#define PT_F(P, Y, C) __builtin_fmaf(P, Y, -(C))
+    const float u0 = fmaxf(fmaxf(fmaxf(PT_F(nearx.x, ynx, cnx), PT_F(neary.x, yny, cny)), PT_F(nearz.x, ynz, cnz)), 0.0f);
+    const float v0 = fminf(fminf(PT_F(farx.x, yfx, cfx), PT_F(fary.x, yfy, cfy)), PT_F(farz.x, yfz, cfz));
+    const float u1 = fmaxf(fmaxf(fmaxf(PT_F(nearx.y, ynx, cnx), PT_F(neary.y, yny, cny)), PT_F(nearz.y, ynz, cnz)), 0.0f);
+    const float v1 = fminf(fminf(PT_F(farx.y, yfx, cfx), PT_F(fary.y, yfy, cfy)), PT_F(farz.y, yfz, cfz));
+    const float u2 = fmaxf(fmaxf(fmaxf(PT_F(nearx.z, ynx, cnx), PT_F(neary.z, yny, cny)), PT_F(nearz.z, ynz, cnz)), 0.0f);
+    const float v2 = fminf(fminf(PT_F(farx.z, yfx, cfx), PT_F(fary.z, yfy, cfy)), PT_F(farz.z, yfz, cfz));
+    const float u3 = fmaxf(fmaxf(fmaxf(PT_F(nearx.w, ynx, cnx), PT_F(neary.w, yny, cny)), PT_F(nearz.w, ynz, cnz)), 0.0f);
+    const float v3 = fminf(fminf(PT_F(farx.w, yfx, cfx), PT_F(fary.w, yfy, cfy)), PT_F(farz.w, yfz, cfz));
+#undef PT_F
+    return (!(u0 > v0) ? 1 : 0) | (!(u1 > v1) ? 2 : 0) | (!(u2 > v2) ? 4 : 0) | (!(u3 > v3) ? 8 : 0);
+}
+#if PT_WIDE_HALF
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+// wide_hit_mask_fma on fp16 planes: the conversion rides in the instruction (v_fma_mix_f32 takes an fp16 operand), so a
+// slot costs six instructions of arithmetic and nothing to unpack.  An fp16 value is an fp32 value: the argument above
+// holds with p = the stored plane, and a stored plane lies outside the box's (lo rounded down, hi rounded up), where
+// the reference's quotient is monotone in the plane.
+__device__ __forceinline__ int wide_hit_mask_fma_h(const half4v nearx, const half4v farx, const half4v neary, const half4v fary,
+                                                   const half4v nearz, const half4v farz, const float ynx, const float yny,
+                                                   const float ynz, const float yfx, const float yfy, const float yfz,
+                                                   const float cnx, const float cny, const float cnz, const float cfx,
+                                                   const float cfy, const float cfz) {
+#define PT_F(P, Y, C) __builtin_fmaf((float)(P), Y, -(C))
+    const float u0 = fmaxf(fmaxf(fmaxf(PT_F(nearx.x, ynx, cnx), PT_F(neary.x, yny, cny)), PT_F(nearz.x, ynz, cnz)), 0.0f);
+    const float v0 = fminf(fminf(PT_F(farx.x, yfx, cfx), PT_F(fary.x, yfy, cfy)), PT_F(farz.x, yfz, cfz));
+    const float u1 = fmaxf(fmaxf(fmaxf(PT_F(nearx.y, ynx, cnx), PT_F(neary.y, yny, cny)), PT_F(nearz.y, ynz, cnz)), 0.0f);
+    const float v1 = fminf(fminf(PT_F(farx.y, yfx, cfx), PT_F(fary.y, yfy, cfy)), PT_F(farz.y, yfz, cfz));
+    const float u2 = fmaxf(fmaxf(fmaxf(PT_F(nearx.z, ynx, cnx), PT_F(neary.z, yny, cny)), PT_F(nearz.z, ynz, cnz)), 0.0f);
+    const float v2 = fminf(fminf(PT_F(farx.z, yfx, cfx), PT_F(fary.z, yfy, cfy)), PT_F(farz.z, yfz, cfz));
+    const float u3 = fmaxf(fmaxf(fmaxf(PT_F(nearx.w, ynx, cnx), PT_F(neary.w, yny, cny)), PT_F(nearz.w, ynz, cnz)), 0.0f);
+    const float v3 = fminf(fminf(PT_F(farx.w, yfx, cfx), PT_F(fary.w, yfy, cfy)), PT_F(farz.w, yfz, cfz));
+#undef PT_F
+    return (!(u0 > v0) ? 1 : 0) | (!(u1 > v1) ? 2 : 0) | (!(u2 > v2) ? 4 : 0) | (!(u3 > v3) ? 8 : 0);
+}
+__device__ __forceinline__ float4v widen(const half4v h) { return float4v{(float)h.x, (float)h.y, (float)h.z, (float)h.w}; }
+#endif
+// the subtract-and-multiply form on scalar reciprocals (the `precise` lanes of a kernel built with the fma form)
+__device__ __forceinline__ int wide_hit_mask_sub(const float4v nearx, const float4v farx, const float4v neary, const float4v fary,
+                                                 const float4v nearz, const float4v farz, const float ox, const float oy,
+                                                 const float oz, const float ynx, const float yny, const float ynz,
+                                                 const float yfx, const float yfy, const float yfz) {
+    return wide_hit_mask(nearx, farx, neary, fary, nearz, farz, ox, oy, oz, float2v{ynx, ynx}, float2v{yny, yny}, float2v{ynz, ynz},
+                         float2v{yfx, yfx}, float2v{yfy, yfy}, float2v{yfz, yfz});
 }
 
 // entry of the per-lane stacks: base << 8 | kindMask << 4 | pendingMask (pending != 0, so an entry is never 0);
@@ -166,7 +240,13 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     unsigned raySlot = 0, queueSlot = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
     int sx = 0, sy = 0, sz = 0;  // 1 where the direction component is negative
+#if PT_TUNE_WIDE_FMA
+    float ynx = 0, yny = 0, ynz = 0, yfx = 0, yfy = 0, yfz = 0;  // y shrunk / grown, see wide_hit_mask
+    float cnx = 0, cny = 0, cnz = 0, cfx = 0, cfy = 0, cfz = 0;  // o y' widened outwards, see wide_hit_mask_fma
+    bool precise = false;  // a tiny direction component: this ray keeps the subtract-and-multiply slot test
+#else
     float2v ynx = {0, 0}, yny = {0, 0}, ynz = {0, 0}, yfx = {0, 0}, yfy = {0, 0}, yfz = {0, 0};  // y shrunk / grown, see wide_hit_mask
+#endif
     float tMin = 0.0f, tMax = 0.0f;
     int bestTri = -1, bestSeq = 0x7fffffff;
     float bestT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;
@@ -255,8 +335,21 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
                     if (!s.handBackAll && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz})) {
                         yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
+#if PT_TUNE_WIDE_FMA
+                        ynx = yx * 0x1.ffffcp-1f; yny = yy * 0x1.ffffcp-1f; ynz = yz * 0x1.ffffcp-1f;
+                        yfx = yx * 0x1.00002p0f; yfy = yy * 0x1.00002p0f; yfz = yz * 0x1.00002p0f;
+                        {
+                            const float ax = ox * ynx, ay = oy * yny, az = oz * ynz, bx = ox * yfx, by = oy * yfy, bz = oz * yfz;
+                            cnx = __builtin_fmaf(__builtin_fabsf(ax), 0x1p-22f, ax); cny = __builtin_fmaf(__builtin_fabsf(ay), 0x1p-22f, ay);
+                            cnz = __builtin_fmaf(__builtin_fabsf(az), 0x1p-22f, az);
+                            cfx = __builtin_fmaf(__builtin_fabsf(bx), -0x1p-22f, bx); cfy = __builtin_fmaf(__builtin_fabsf(by), -0x1p-22f, by);
+                            cfz = __builtin_fmaf(__builtin_fabsf(bz), -0x1p-22f, bz);
+                        }
+                        precise = !(mag_within(dx, -12, kDirHi) && mag_within(dy, -12, kDirHi) && mag_within(dz, -12, kDirHi));
+#else
                         ynx = (float2v)(yx * 0x1.ffffcp-1f); yny = (float2v)(yy * 0x1.ffffcp-1f); ynz = (float2v)(yz * 0x1.ffffcp-1f);
                         yfx = (float2v)(yx * 0x1.00002p0f); yfy = (float2v)(yy * 0x1.00002p0f); yfz = (float2v)(yz * 0x1.00002p0f);
+#endif
                         sx = dx < 0.0f ? 1 : 0; sy = dy < 0.0f ? 1 : 0; sz = dz < 0.0f ? 1 : 0;
                         bestTri = -1; bestSeq = 0x7fffffff; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
                         w = 0;
@@ -290,6 +383,37 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
             if (COUNT) { const unsigned long long ma = __ballot(w >= 0 && groups < kWideGroups); if (ma) { nv += (w >= 0 && groups < kWideGroups) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; } }
 #endif
             if (w >= 0 && groups < kWideGroups) {
+#if PT_WIDE_HALF
+                // four 16-B rows per node from either home: x, y, z planes as halves {lo0..3, hi0..3}, meta
+                half8v rx, ry, rz;
+                float4v meta;
+                if (w < nTop) {  // top of the tree: from LDS
+                    const __attribute__((address_space(3))) char* at = (const __attribute__((address_space(3))) char*)topLds + ((unsigned)w << 6);
+                    rx = *(const __attribute__((address_space(3))) half8v*)at;
+                    ry = *(const __attribute__((address_space(3))) half8v*)(at + 16);
+                    rz = *(const __attribute__((address_space(3))) half8v*)(at + 32);
+                    meta = *(const __attribute__((address_space(3))) float4v*)(at + 48);
+                } else {
+                    const __attribute__((address_space(1))) char* at = (const __attribute__((address_space(1))) char*)nodesGlobal + ((size_t)(unsigned)w << 6);
+                    rx = *(const __attribute__((address_space(1))) half8v*)at;
+                    ry = *(const __attribute__((address_space(1))) half8v*)(at + 16);
+                    rz = *(const __attribute__((address_space(1))) half8v*)(at + 32);
+                    meta = *(const __attribute__((address_space(1))) float4v*)(at + 48);
+                }
+                const int masks = f2i(meta.z);
+                const int imask = masks & 15, lmask = (masks >> 4) & 15;
+#if !PT_DIAG_UTIL
+                if (COUNT) nv += (unsigned)__popc((unsigned)(imask | lmask));
+#endif
+                // near = the plane the ray meets first along the axis: lo where d > 0, hi where d < 0
+                const half4v nearx = sx ? rx.hi : rx.lo, farx = sx ? rx.lo : rx.hi;
+                const half4v neary = sy ? ry.hi : ry.lo, fary = sy ? ry.lo : ry.hi;
+                const half4v nearz = sz ? rz.hi : rz.lo, farz = sz ? rz.lo : rz.hi;
+                const int hm = precise ? wide_hit_mask_sub(widen(nearx), widen(farx), widen(neary), widen(fary), widen(nearz), widen(farz),
+                                                           ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz)
+                                       : wide_hit_mask_fma_h(nearx, farx, neary, fary, nearz, farz, ynx, yny, ynz, yfx, yfy, yfz, cnx, cny,
+                                                             cnz, cfx, cfy, cfz);
+#else
                 float4v nearx, farx, neary, fary, nearz, farz, meta;  // rows picked by the direction signs (sx, sy, sz)
                 // byte offsets of the seven rows inside the record, the same for both homes of a node; 32-bit
                 // offsets from a uniform base let the loads address with base + offset instead of 64-bit sums
@@ -314,7 +438,14 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
 #if !PT_DIAG_UTIL
                 if (COUNT) nv += (unsigned)__popc((unsigned)(imask | lmask));
 #endif
+#if PT_TUNE_WIDE_FMA
+                const int hm = precise ? wide_hit_mask_sub(nearx, farx, neary, fary, nearz, farz, ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz)
+                                       : wide_hit_mask_fma(nearx, farx, neary, fary, nearz, farz, ynx, yny, ynz, yfx, yfy, yfz, cnx, cny, cnz,
+                                                           cfx, cfy, cfz);
+#else
                 const int hm = wide_hit_mask(nearx, farx, neary, fary, nearz, farz, ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz);
+#endif
+#endif
                 const int lh = hm & lmask, ih = hm & imask;
                 if (lh != 0) {  // park the candidate leaves of this node as one group
 #pragma unroll
