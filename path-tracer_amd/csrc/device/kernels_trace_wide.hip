@@ -37,7 +37,7 @@ namespace ptd {
 #define PT_TUNE_WIDE_WAVES 4
 #endif
 #ifndef PT_TUNE_WIDE_BURST
-#define PT_TUNE_WIDE_BURST 8          // visits between two votes, closest hit (4: 5.96 ms per bench launch, 6: 5.85, 8: 5.81)
+#define PT_TUNE_WIDE_BURST 12         // visits between two votes, closest hit (r2, fp16 nodes: 6: 5.42 ms per bench launch, 8: 5.25, 12: 5.07, 16: 5.09, 24: 5.35)
 #endif
 #ifndef PT_TUNE_WIDE_REFILL
 #define PT_TUNE_WIDE_REFILL 16
@@ -68,13 +68,13 @@ namespace ptd {
 #define PT_TUNE_WIDE_BURST_ANYHIT 4   // ... any hit: rays end early, shorter bursts waste fewer visits (3: 1.70 ms, 4: 1.62, 6: 1.67)
 #endif
 #ifndef PT_TUNE_WIDE_LEAF_ANYHIT
-#define PT_TUNE_WIDE_LEAF_ANYHIT PT_TUNE_WIDE_LEAF
+#define PT_TUNE_WIDE_LEAF_ANYHIT 32    // any-hit rays hold fewer leaves: start their leaf phase earlier (r2: 40/8/16 1.50 ms per bench launch, 32/16/8 1.41)
 #endif
 #ifndef PT_TUNE_WIDE_KEEP_ANYHIT
-#define PT_TUNE_WIDE_KEEP_ANYHIT PT_TUNE_WIDE_KEEP
+#define PT_TUNE_WIDE_KEEP_ANYHIT 8
 #endif
 #ifndef PT_TUNE_WIDE_STUCK_ANYHIT
-#define PT_TUNE_WIDE_STUCK_ANYHIT PT_TUNE_WIDE_STUCK
+#define PT_TUNE_WIDE_STUCK_ANYHIT 16
 #endif
 constexpr int kWideBlock = PT_TUNE_WIDE_BLOCK;
 #ifndef PT_TUNE_WIDE_GROUPS

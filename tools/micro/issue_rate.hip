@@ -107,6 +107,26 @@ __global__ void k(float* out, int iters, long long* cyc) {
             for (int r = 0; r < 8; r++)
                 asm volatile("v_cmp_gt_f32 s[20:21], %0, %1\n v_cmp_gt_f32 s[22:23], %1, %2\n v_cmp_gt_f32 s[24:25], %2, %3\n v_cmp_gt_f32 s[26:27], %3, %0\n"
                              ::"v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        } else if (MODE == 19) {  // 32 v_fma_mix_f32 (fp16 operand converted in the instruction), 8 independent
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_fma_mix_f32 %0, %8, %0, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %1, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %2, %8, %2, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %8, %3, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %4, %8, %4, %4 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %5, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %6, %8, %6, %6 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %7, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(0x3c003c00));
+        } else if (MODE == 20) {  // 32 v_add_u32, 8 independent
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                             "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(3));
+        } else if (MODE == 21) {  // 32 v_and_b32 / v_lshlrev_b32 alternating, 8 independent
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                asm volatile("v_and_b32 %0, %0, %8\n v_lshlrev_b32 %1, 1, %1\n v_and_b32 %2, %2, %8\n v_lshlrev_b32 %3, 1, %3\n"
+                             "v_and_b32 %4, %4, %8\n v_lshlrev_b32 %5, 1, %5\n v_and_b32 %6, %6, %8\n v_lshlrev_b32 %7, 1, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(0x7fffffff));
         } else if (MODE == 5) {  // 16 x (v_cmp + s_and_saveexec-like scalar mask op)
 #pragma unroll
             for (int r = 0; r < 16; r++)
@@ -157,7 +177,7 @@ int main(int argc, char** argv) {
         if (run<1>("s_add_u32 x32", 32)) return 1;
         if (run<2>("v_fma + s_add x16 each", 32)) return 1;
         if (run<5>("v_cmp + s_and x16 each", 32)) return 1;
-    } else {
+    } else if (which == 1) {
         if (run<11>("v_mul_f32_e32 x32", 32)) return 1;
         if (run<12>("v_min_f32_e32 x32", 32)) return 1;
         if (run<13>("v_mov_b32 x32", 32)) return 1;
@@ -166,6 +186,10 @@ int main(int argc, char** argv) {
         if (run<18>("v_cmp_gt_f32 sgpr x32", 32)) return 1;
         if (run<16>("saveexec + or exec x16", 32)) return 1;
         if (run<17>("s_cbranch_execz (not taken) x32", 32)) return 1;
+    } else if (which == 2) {
+        if (run<19>("v_fma_mix_f32 x32", 32)) return 1;
+        if (run<20>("v_add_u32 x32", 32)) return 1;
+        if (run<21>("v_and_b32 / v_lshlrev_b32 x32", 32)) return 1;
     }
     return 0;
 }
