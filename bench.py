@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--bvh", choices=("reference", "all-axes"), default="reference",
                     help="all-axes: the three-axis SAH build (SURVEY 8(f).1), NOT the reference's tree and not the headline")
     ap.add_argument("--detail", type=int, default=1, help="sponza-standin tessellation (1: 65,536 tris, 2: 256,768)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="serialise shadow-ray and extension-ray launches on one stream in the timed loop too (for rocprofv3 "
+                         "--kernel-trace runs: overlapped kernels' begin-to-end times include waiting for CUs)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the N-rank plumbing (launcher, rendezvous over gloo, tile gather, barrier, "
                          "max-over-ranks timing, rank 0's JSON line) with the render replaced by filling the owned pixels: "
@@ -258,7 +261,7 @@ def main():
             gatherer.gather(rgb)  # no-op on one GPU
 
         accum.zero_()
-        ctx.set_overlap(not profile)
+        ctx.set_overlap(not profile and not args.no_overlap)
         for _ in range(args.warmup):
             step()
         sync()
@@ -272,7 +275,7 @@ def main():
         elapsed = time.perf_counter() - t0
         st = ctx.stats()
         ctx.set_profiling(False)
-        ctx.set_overlap(True)
+        ctx.set_overlap(not args.no_overlap)
         return elapsed, st, state["sample"] - args.steps * spp_per_step
 
     def reduce_over_ranks(elapsed, st):

@@ -55,7 +55,10 @@ for k, d in out.items():
             print(f"    {c}: {d[c]:.4g}")
 if "--traffic" in sys.argv:
     sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tools"))
     import bench  # kernel_source_hash(): bench.py reports these counters only for the sources they were recorded for
+    import valu_cost
+    costs = valu_cost.kernel_costs()
     t = {"kernel_source_hash": bench.kernel_source_hash(), "recorded_as": f"profiles/{rnd}/pmc_{tag}.json"}
     for k in ("k_trace_closest", "k_trace_occluded", "k_trace_wide_closest", "k_trace_wide_occluded"):
         if k in out and "hbm_read_bytes_per_launch" in out[k]:
@@ -66,16 +69,17 @@ if "--traffic" in sys.argv:
             if out[k].get("SQ_INSTS_VALU") and out[k].get("GRBM_GUI_ACTIVE"):
                 # Vector-ALU issue-slot occupancy.  SQ_ACTIVE_INST_VALU ticks once per VALU instruction on this part
                 # whatever the instruction costs (profiles/README.md, "unit of SQ_ACTIVE_INST_VALU"), so it is not a
-                # busy time; instead: instructions x issue cost per class (tools/micro/issue_rate.hip: fp32 add / mul /
-                # fma 2 cycles per wave64 instruction, everything else -- min/max/cmp/cndmask/packed/int/mov with
-                # SGPR operands -- 4) over SIMDs x kernel cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024
-                # SIMDs on the chip).
+                # busy time; instead: executed instructions x the mean issue cost of the kernel's instructions
+                # (tools/valu_cost.py: the compiled kernel's mix priced with tools/micro/issue_rate.hip's cycles at
+                # 4 wavefronts per SIMD) over SIMDs x kernel cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024
+                # SIMDs on the chip).  lo / hi: every instruction at 2.8 / at 4.5 cycles.
                 o = out[k]
-                cheap = sum(o.get(c, 0.0) for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
-                have_mix = any(c in o for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
-                cyc = (2.0 * cheap + 4.0 * (o["SQ_INSTS_VALU"] - cheap)) if have_mix else 4.0 * o["SQ_INSTS_VALU"]
-                t[k]["valu_issue_occupancy"] = (cyc / 1024.0) / (o["GRBM_GUI_ACTIVE"] / 8.0)
-                t[k]["valu_issue_occupancy_basis"] = "measured class mix" if have_mix else "upper bound: every instruction at 4 cycles"
+                mean = costs.get(k, {}).get("mean_issue_cycles", 4.5)
+                per_simd = o["SQ_INSTS_VALU"] / 1024.0
+                cyc = o["GRBM_GUI_ACTIVE"] / 8.0
+                t[k]["valu_issue_occupancy"] = per_simd * mean / cyc
+                t[k]["valu_issue_occupancy_range"] = [per_simd * 2.8 / cyc, per_simd * 4.5 / cyc]
+                t[k]["valu_mean_issue_cycles"] = mean
                 if o.get("lanes_per_valu_inst"):
                     t[k]["lanes_per_valu_inst"] = o["lanes_per_valu_inst"]
                     t[k]["useful_lane_frac"] = t[k]["valu_issue_occupancy"] * o["lanes_per_valu_inst"] / 64.0
