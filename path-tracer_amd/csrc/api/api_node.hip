@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -34,7 +35,11 @@ struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;  // an RCCL extension: may be absent
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -57,8 +62,14 @@ const Rccl* load_rccl() {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
     r.Gather = (decltype(r.Gather))dlsym(h, "ncclGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!r.CommInitAll || !r.CommDestroy || !r.Gather || !r.GetErrorString) {
-        g_rccl.error = "RCCL lacks ncclCommInitAll / ncclCommDestroy / ncclGather / ncclGetErrorString";
+    r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(h, "ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+    if (getenv("MIPT_NODE_NO_NCCLGATHER")) r.Gather = nullptr;  // tests: take the grouped send / receive path
+    const bool p2p = r.Send && r.Recv && r.GroupStart && r.GroupEnd;
+    if (!r.CommInitAll || !r.CommDestroy || !r.GetErrorString || (!r.Gather && !p2p)) {
+        g_rccl.error = "RCCL lacks ncclCommInitAll / ncclCommDestroy / ncclGetErrorString, or both ncclGather and ncclSend / ncclRecv";
         dlclose(h);
         return nullptr;
     }
@@ -195,8 +206,18 @@ int render_rank_gather(mipt_node* nd, int ri) {
     Rank& r = nd->ranks[(size_t)ri];
     if (nd->n > 1 || nd->useRccl) {
         if (nd->useRccl) {
-            const ncclResult_t e = nd->rccl->Gather(r.send, r.recv, nd->slotFloats, ncclFloat, 0, r.comm, r.stream);
-            if (e != ncclSuccess) { r.error = std::string("ncclGather failed: ") + nd->rccl->GetErrorString(e); return MIPT_ERR_DEVICE; }
+            ncclResult_t e;
+            if (nd->rccl->Gather) {
+                e = nd->rccl->Gather(r.send, r.recv, nd->slotFloats, ncclFloat, 0, r.comm, r.stream);
+            } else {  // the same exchange as one group of point-to-point operations: every rank sends, rank 0 receives N
+                e = nd->rccl->GroupStart();
+                if (e == ncclSuccess) e = nd->rccl->Send(r.send, nd->slotFloats, ncclFloat, 0, r.comm, r.stream);
+                for (int k = 0; ri == 0 && k < nd->n && e == ncclSuccess; k++)
+                    e = nd->rccl->Recv(r.recv + (size_t)k * nd->slotFloats, nd->slotFloats, ncclFloat, k, r.comm, r.stream);
+                const ncclResult_t e2 = nd->rccl->GroupEnd();
+                if (e == ncclSuccess) e = e2;
+            }
+            if (e != ncclSuccess) { r.error = std::string("RCCL gather failed: ") + nd->rccl->GetErrorString(e); return MIPT_ERR_DEVICE; }
         } else {  // ranks share a GPU: a device-to-device copy into rank 0's slot, ordered by an event
             hipError_t ce = hipSuccess;
             if (ri != 0) {

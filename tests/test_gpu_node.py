@@ -78,3 +78,27 @@ def test_node_errors(B, setup):
     with pytest.raises(B.MiptError):   # every rank refuses the same bad mode before the gather: no rank is left waiting
         node.render(cam, mode=7)
     assert np.array_equal(bits(node.render(cam, mode=B.MODE_DIRECT)), bits(setup[4]))  # and the node still works
+
+
+def test_grouped_send_receive_path_in_a_fresh_process(B, setup, tmp_path):
+    """ncclGather is an RCCL extension; a build of the library without it gathers with one group of ncclSend / ncclRecv.
+    MIPT_NODE_NO_NCCLGATHER=1 forces that path (decided when RCCL is first loaded, hence a fresh process): the 1-GPU
+    node's frame must again equal the one-context frame bit for bit."""
+    import os, subprocess, sys
+    script = tmp_path / "p2p.py"
+    script.write_text(
+        "import importlib, sys, numpy as np\n"
+        f"sys.path[:0] = [{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}, {os.path.dirname(os.path.abspath(__file__))!r}]\n"
+        "import scene_fixtures as sf\n"
+        "B = importlib.import_module('path-tracer_amd').binding\n"
+        "scene = sf.product_scene_from_mesh_arrays(*sf.load_scene_arrays('cornellbox-glass'), env=sf.procedural_env(64))\n"
+        "cam = B.default_camera(200, 150)\n"
+        "ref = B.Context(scene, device=0).render(cam, mode=B.MODE_PATH, spp=3, max_bounces=4, seed=3)\n"
+        "node = B.Node(scene, ngpus=1)\n"
+        "assert node.uses_rccl\n"
+        "img = node.render(cam, mode=B.MODE_PATH, spp=3, max_bounces=4, seed=3)\n"
+        "assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))\n"
+        "print('p2p ok')\n")
+    env = dict(os.environ, MIPT_NODE_NO_NCCLGATHER="1")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and "p2p ok" in r.stdout, r.stderr[-2000:]
