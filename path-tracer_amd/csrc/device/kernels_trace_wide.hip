@@ -39,6 +39,12 @@ namespace ptd {
 #ifndef PT_TUNE_WIDE_BURST
 #define PT_TUNE_WIDE_BURST 12         // visits between two votes, closest hit (r2, fp16 nodes: 6: 5.42 ms per bench launch, 8: 5.25, 12: 5.07, 16: 5.09, 24: 5.35)
 #endif
+#ifndef PT_TUNE_WIDE_STATIC_SHIFT
+#define PT_TUNE_WIDE_STATIC_SHIFT 2   // the static first chunks cover 1 - 2^-shift of the queue
+#endif
+#ifndef PT_TUNE_WIDE_CHUNK_MIN
+#define PT_TUNE_WIDE_CHUNK_MIN 128u   // smallest chunk the cursor hands out (r2: 64 -> 128: a 1 M-ray launch 152 -> 131 us, a 1/8 share of the bench step 6.5 -> 6.3 ms, the whole step unchanged; 256: the same)
+#endif
 #ifndef PT_TUNE_WIDE_REFILL
 #define PT_TUNE_WIDE_REFILL 16
 #endif
@@ -269,9 +275,26 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     // is where both traversal kernels stood.  Guided self-scheduling: a wavefront asks for half of its share of
     // what was left when it last looked (64..1024 rays), so chunks are large while the queue is long and shrink
     // to 64 at the end, where they decide how evenly the wavefronts finish.
+    // The FIRST chunk of every wavefront is static: wavefront k owns rays [k c0, (k + 1) c0) with c0 = its share of
+    // three quarters of the queue (PT_TUNE_WIDE_STATIC_SHIFT; 64..1024), and the cursor hands out what lies behind nWaves c0.  A launch starts
+    // with all 4,096 wavefronts asking at once, and one that fits the static part (262,144 rays at c0 = 64: config 1)
+    // ended with 4,096 more atomics that only said "empty": 2 x 4,096 x 12 ns = the 100 us such a launch took for 8 us
+    // of instructions (SQ_INSTS_VALU / SQ_WAVE_CYCLES of the launch).  A 1 M-ray launch spent 16,384 atomics (all
+    // chunks at the 64-ray floor) = 0.2 ms of its 0.34 ms the same way.
     const unsigned nWaves = gridDim.x * (unsigned)(kWideBlock / 64);
-    unsigned lastBase = 0;
-    bool exhausted = (total == 0);
+    const unsigned gw = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)(kWideBlock / 64) + (threadIdx.x >> 6)));
+    unsigned c0 = ((total - (total >> PT_TUNE_WIDE_STATIC_SHIFT)) / nWaves) & ~63u;
+    c0 = c0 < 64u ? 64u : (c0 > 1024u ? 1024u : c0);
+    const unsigned long long staticAll = (unsigned long long)nWaves * c0;
+    const unsigned dynBase = staticAll < (unsigned long long)total ? (unsigned)staticAll : total;  // cursor value 0 = this ray
+    {
+        const unsigned long long first = (unsigned long long)gw * c0;
+        chunkBase = first < (unsigned long long)total ? (unsigned)first : total;
+        chunkLeft = (total - chunkBase) < c0 ? (total - chunkBase) : c0;
+        if (q.counts && chunkLeft != 0) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= chunkBase));
+    }
+    unsigned lastBase = dynBase;
+    bool exhausted = (chunkLeft == 0 && dynBase >= total);
 
 #define PT_FINISH()                                                                        \
     do {                                                                                   \
@@ -300,11 +323,14 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
         if (!exhausted && nEmpty >= (ANYHIT ? PT_TUNE_WIDE_REFILL_ANYHIT : PT_TUNE_WIDE_REFILL)) {
             // ---- refill: empty lanes take the next rays of the queue ----
             if (chunkLeft == 0) {
-                unsigned base = 0;
+                unsigned base = total;
                 unsigned chunkRays = ((total - lastBase) / (nWaves * 2u)) & ~63u;
-                chunkRays = chunkRays < 64u ? 64u : (chunkRays > 1024u ? 1024u : chunkRays);
-                if (lane == 0) base = atomicAdd(cursor, chunkRays);
-                base = __shfl(base, 0);
+                chunkRays = chunkRays < PT_TUNE_WIDE_CHUNK_MIN ? PT_TUNE_WIDE_CHUNK_MIN : (chunkRays > 1024u ? 1024u : chunkRays);
+                if (dynBase < total) {  // otherwise the static chunks were the whole queue: nothing to ask for
+                    if (lane == 0) base = atomicAdd(cursor, chunkRays);
+                    base = __shfl(base, 0);
+                    base = base < total - dynBase ? dynBase + base : total;
+                }
                 if (base >= total) {
                     exhausted = true;
                 } else {

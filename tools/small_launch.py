@@ -1,8 +1,11 @@
 import sys, numpy as np, importlib
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
 import scene_fixtures as sf
 B = importlib.import_module('path-tracer_amd').binding
-arrays = sf.sponza_standin(1)
+name = sys.argv[1] if len(sys.argv) > 1 else 'sponza'
+arrays = sf.sponza_standin(1) if name == 'sponza' else sf.load_scene_arrays(name)
 scene = sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT)
 ctx = B.Context(scene, device=0)
 pos = np.asarray(arrays[0], np.float32).reshape(-1, 3); lo, hi = pos.min(0), pos.max(0)
