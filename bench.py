@@ -83,29 +83,40 @@ def spawn_ranks(n):
     """`python bench.py --gpus N` typed without a launcher: start the N ranks as children of this process -- which has
     not imported torch or touched the GPU -- with the environment torch.distributed.run would give them, relay rank 0's
     output, exit with the worst exit code.  Children are killed by their own pids if one of them fails or overstays."""
+    import tempfile
     port = _free_port()
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    rc, out0 = 0, ""
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rc = 0
     deadline = time.time() + 1500.0
     try:
-        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
-        for pr in procs:
-            pr.wait(timeout=max(1.0, deadline - time.time()))
-            rc = rc or pr.returncode
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while True:
+            codes = [pr.poll() for pr in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:  # a rank that died leaves the others waiting in a rendezvous or a collective: end them
+                rc = bad[0]
+                print(f"bench.py: rank {codes.index(bad[0])} exited with status {bad[0]}; stopping the other ranks", file=sys.stderr)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                rc = 124
+                print("bench.py: ranks still running after 1500 s; stopping them", file=sys.stderr)
+                break
+            time.sleep(0.1)
     finally:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
                 pr.wait()
-    sys.stdout.write(out0)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
     return rc
 
@@ -199,6 +210,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="serialise shadow-ray and extension-ray launches on one stream in the timed loop too (for rocprofv3 "
                          "--kernel-trace runs: overlapped kernels' begin-to-end times include waiting for CUs)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the per-step gather, barriers and reductions even with one "
+                         "rank: the N > 1 code path on a one-GPU box (tests/test_gpu_node.py)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the N-rank plumbing (launcher, rendezvous over gloo, tile gather, barrier, "
                          "max-over-ranks timing, rank 0's JSON line) with the render replaced by filling the owned pixels: "
@@ -227,7 +241,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist  # the collectives run
+    if multi:
+        if "MASTER_ADDR" not in os.environ:  # --force-dist typed without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- scene: host-side load/build, then one arena upload ----
@@ -240,11 +257,11 @@ def main():
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
     rgb = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
 
-    gatherer = pkg.tiles.TileGather(W, H, rank, world, dev, TILE_W, TILE_H)  # owned pixels -> rank 0, one RCCL gather per step
+    gatherer = pkg.tiles.TileGather(W, H, rank, world, dev, TILE_W, TILE_H, always=args.force_dist)  # owned pixels -> rank 0, one RCCL gather per step
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -281,7 +298,7 @@ def main():
     def reduce_over_ranks(elapsed, st):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         rays = torch.tensor([float(st["rays_closest"] + st["rays_occluded"])], dtype=torch.float64, device=dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         return float(t.item()), float(rays.item())
@@ -311,7 +328,7 @@ def main():
     del accum2, rgb2
 
     weak = None
-    if world > 1:  # per-GPU work fixed: N frames' worth of samples per step
+    if multi:  # per-GPU work fixed: N frames' worth of samples per step
         w_elapsed, w_st, _ = timed_loop(args.spp * world)
         w_max, w_rays = reduce_over_ranks(w_elapsed, w_st)
         weak = {"value": w_rays / w_max / 1e6, "unit": "Mrays/s", "ms_per_step": w_max / args.steps * 1e3,
@@ -422,7 +439,7 @@ def main():
             except Exception as e:
                 out["cpu_baseline"]["all_cores"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return 0
@@ -433,6 +450,9 @@ def dry_run(args, rank, world, torch, dist, pkg):
     rank 0 once per step, steps are bracketed by barriers, the time is the max over ranks, rank 0 checks the assembled
     frame and prints the JSON line (value 0: nothing is measured here)"""
     w, h = 320, 200
+    if os.environ.get("MIPT_BENCH_TEST_DIE_RANK") == str(rank):  # tests: a rank that dies before the rendezvous
+        print(f"rank {rank}: dying on request", file=sys.stderr)
+        return 3
     if world > 1:
         dist.init_process_group("gloo")
     g = pkg.tiles.TileGather(w, h, rank, world, torch.device("cpu"), TILE_W, TILE_H)

@@ -32,9 +32,10 @@ def owned_pixel_indices(width, height, parts, tile_w=TILE_W, tile_h=TILE_H):
 class TileGather:
     """Pre-allocated buffers + index tensors for the per-step gather."""
 
-    def __init__(self, width, height, rank, world, device, tile_w=TILE_W, tile_h=TILE_H):
+    def __init__(self, width, height, rank, world, device, tile_w=TILE_W, tile_h=TILE_H, always=False):
+        """always: run the collective even in a world of one rank (rehearsing the RCCL path on a one-GPU box)"""
         import torch
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.always = rank, world, always
         self.idx = [torch.from_numpy(i).to(device) for i in owned_pixel_indices(width, height, world, tile_w, tile_h)]
         self.max_own = max(int(i.numel()) for i in self.idx)
         self.send = torch.zeros(self.max_own * 3, dtype=torch.float32, device=device)
@@ -49,7 +50,7 @@ class TileGather:
         """rgb_flat: this rank's frame buffer as a flat float tensor of width*height*3; on rank 0 the pixels
         of the other ranks are written into it"""
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         rgb3 = rgb_flat.view(-1, 3)
         n = self.idx[self.rank].numel()
@@ -66,7 +67,7 @@ class TileGather:
         of width*height*3; rank 0 receives a quarter of the bytes of gather()"""
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         if not hasattr(self, "send8"):
             dev = self.send.device

@@ -45,6 +45,16 @@ def test_world_size_mismatch_is_an_error():
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
+def test_a_rank_that_dies_ends_the_whole_run_at_once():
+    """one rank exits before the rendezvous (on a GPU box: an invalid device ordinal); the others wait for it in
+    init_process_group for minutes -- the parent must stop them and report the status, not hang with them"""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"], env_extra={"MIPT_BENCH_TEST_DIE_RANK": "1"})
+    assert r.returncode == 3 and "rank 1 exited with status 3" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 60
+
+
 def test_kernel_source_hash_guards_the_pmc_counters():
     """bench.py reports PMC-derived figures only when profiles/traffic.json was recorded for the current kernel sources"""
     sys.path.insert(0, ROOT)

@@ -102,3 +102,21 @@ def test_grouped_send_receive_path_in_a_fresh_process(B, setup, tmp_path):
     env = dict(os.environ, MIPT_NODE_NO_NCCLGATHER="1")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=200)
     assert r.returncode == 0 and "p2p ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_rccl_path_with_one_rank(tmp_path):
+    """bench.py's N > 1 code path -- RCCL process group bound to the device, per-step tile gather on device tensors,
+    barriers, MAX / SUM reductions, the weak-scaling loop -- run with ONE rank (--force-dist), which is all a one-GPU box
+    allows; the headline must equal what the plain run reports for the same frames (same rays, a sane rate)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--force-dist"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 1000.0
+    weak = out["config"]["weak_scaling"]
+    assert weak is not None and weak["spp_per_step"] == 16 and abs(weak["value"] / out["value"] - 1.0) < 0.1
