@@ -138,51 +138,310 @@ static bool is_binary_tree(const mipt_scene_desc* d) {
     return true;
 }
 
-// Builds the 4-wide node array from the threaded binary tree: a wide node stands for a binary interior node, its (up
+// The binary tree build_wide collapses: either the reference's own (copied from the descriptor) or a hierarchy of
+// our own over the reference's LEAVES (rebuild_top).  refLeaf[i] >= 0 marks a leaf and names the reference node whose
+// exact box, leaf_first and leaf_count it stands for.
+struct BinTree {
+    std::vector<float> mn, mx;  // 3 per node
+    std::vector<int> left, right, refLeaf;
+    int add(const float* lo, const float* hi, int ref) {
+        for (int a = 0; a < 3; a++) { mn.push_back(lo[a]); mx.push_back(hi[a]); }
+        left.push_back(-1); right.push_back(-1); refLeaf.push_back(ref);
+        return (int)refLeaf.size() - 1;
+    }
+    int size() const { return (int)refLeaf.size(); }
+};
+
+// A hierarchy of our own over the reference's leaves.  The order-free traversal needs the reference's LEAVES (their
+// exact boxes, their triangles in leafTris order) and above them any hierarchy whose boxes contain what lies below
+// (kernels_trace_wide.hip: a leaf whose exact box passes the exact predicate is reached through every ancestor whose
+// stored box contains it, because the conservative slot test is monotone in the planes).  The reference's upper tree
+// is one such hierarchy, but not a good one: its SAH sweep looks at the longest axis only (cs488.h:1463) and its
+// binary shape was not made to be collapsed four wide.  Here: a top-down SAH build over the leaf boxes, exact sweep
+// along all three axes at every node, weights = triangles per leaf.  Same leaves, same admission test, same
+// tie-break, hence the same hits bit for bit -- with fewer node visits per ray.
+static void rebuild_top(const mipt_scene_desc* d, BinTree& t) {
+    struct Leaf { float lo[3], hi[3], c[3]; int ref, w; };
+    std::vector<Leaf> leaves;
+    for (int i = 0; i < d->n_nodes; i++) {
+        if (d->leaf_count[i] <= 0) continue;
+        Leaf l;
+        for (int a = 0; a < 3; a++) {
+            l.lo[a] = d->node_min[3 * i + a]; l.hi[a] = d->node_max[3 * i + a];
+            l.c[a] = 0.5f * l.lo[a] + 0.5f * l.hi[a];
+        }
+        l.ref = i; l.w = d->leaf_count[i];
+        leaves.push_back(l);
+    }
+    const int nl = (int)leaves.size();
+    std::vector<int> idx((size_t)nl);
+    for (int i = 0; i < nl; i++) idx[(size_t)i] = i;
+    auto area = [](const float* lo, const float* hi) -> double {
+        const double ex = (double)hi[0] - lo[0], ey = (double)hi[1] - lo[1], ez = (double)hi[2] - lo[2];
+        return ex * ey + ey * ez + ez * ex;
+    };
+    auto grow = [](float* lo, float* hi, const Leaf& l) {
+        for (int a = 0; a < 3; a++) { if (l.lo[a] < lo[a]) lo[a] = l.lo[a]; if (l.hi[a] > hi[a]) hi[a] = l.hi[a]; }
+    };
+    struct Job { int begin, end, node; };
+    std::vector<Job> jobs;
+    std::vector<double> rightArea;
+    std::vector<long long> rightW;
+    std::vector<int> best, tmp;
+    auto boxOf = [&](int begin, int end, float* lo, float* hi) {
+        for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+        for (int k = begin; k < end; k++) grow(lo, hi, leaves[(size_t)idx[(size_t)k]]);
+    };
+    {
+        float lo[3], hi[3];
+        boxOf(0, nl, lo, hi);
+        if (nl == 1) { t.add(lo, hi, leaves[0].ref); return; }
+        jobs.push_back({0, nl, t.add(lo, hi, -1)});
+    }
+    while (!jobs.empty()) {
+        const Job j = jobs.back();
+        jobs.pop_back();
+        const int cnt = j.end - j.begin;
+        double bestCost = INFINITY;
+        int bestSplit = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            tmp.assign(idx.begin() + j.begin, idx.begin() + j.end);
+            std::sort(tmp.begin(), tmp.end(), [&](int x, int y) {
+                const float cx = leaves[(size_t)x].c[axis], cy = leaves[(size_t)y].c[axis];
+                return cx < cy || (cx == cy && x < y);
+            });
+            rightArea.assign((size_t)cnt + 1, 0.0);
+            rightW.assign((size_t)cnt + 1, 0);
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int k = cnt - 1; k > 0; k--) {
+                grow(lo, hi, leaves[(size_t)tmp[(size_t)k]]);
+                rightArea[(size_t)k] = area(lo, hi);
+                rightW[(size_t)k] = rightW[(size_t)k + 1] + leaves[(size_t)tmp[(size_t)k]].w;
+            }
+            for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+            long long wl = 0;
+            for (int k = 1; k < cnt; k++) {  // split before position k: [0, k) | [k, cnt)
+                grow(lo, hi, leaves[(size_t)tmp[(size_t)k - 1]]);
+                wl += leaves[(size_t)tmp[(size_t)k - 1]].w;
+                const double cost = area(lo, hi) * (double)wl + rightArea[(size_t)k] * (double)rightW[(size_t)k];
+                if (cost < bestCost) { bestCost = cost; bestSplit = k; best = tmp; }
+            }
+        }
+        if (bestSplit < 0) { bestSplit = cnt / 2; best.assign(idx.begin() + j.begin, idx.begin() + j.end); }  // NaN-free input never gets here
+        std::copy(best.begin(), best.end(), idx.begin() + j.begin);
+        const int mid = j.begin + bestSplit;
+        int child[2];
+        const int range[2][2] = {{j.begin, mid}, {mid, j.end}};
+        for (int side = 0; side < 2; side++) {
+            float lo[3], hi[3];
+            boxOf(range[side][0], range[side][1], lo, hi);
+            const bool leaf = range[side][1] - range[side][0] == 1;
+            child[side] = t.add(lo, hi, leaf ? leaves[(size_t)idx[(size_t)range[side][0]]].ref : -1);
+            if (!leaf) jobs.push_back({range[side][0], range[side][1], child[side]});
+        }
+        t.left[(size_t)j.node] = child[0];
+        t.right[(size_t)j.node] = child[1];
+    }
+}
+
+// Insertion-based optimisation of a binary hierarchy (after Bittner, Hapala, Havran 2013): take a subtree out (its
+// parent goes with it, the sibling moves up), find by branch and bound the place where putting it back adds the least
+// surface area to the tree (the new parent's box plus what the ancestors grow by), put it there.  Putting it back where
+// it was is one of the candidates, so the sum of interior box areas -- the expected number of node visits -- never
+// grows.  Nodes are tried largest box first, in passes, until a pass gains under half a per cent.  Afterwards the
+// nodes are renumbered parents first (the collapse sweeps rely on children having larger ids).
+static void optimise_top(BinTree& t) {
+    const int n = t.size();
+    if (n < 7) return;
+    std::vector<int> parent((size_t)n, -1);
+    for (int i = 0; i < n; i++)
+        if (t.refLeaf[(size_t)i] < 0) { parent[(size_t)t.left[(size_t)i]] = i; parent[(size_t)t.right[(size_t)i]] = i; }
+    int root = 0;
+    auto areaOf = [&](int v) -> double {
+        const double ex = (double)t.mx[3 * (size_t)v] - t.mn[3 * (size_t)v], ey = (double)t.mx[3 * (size_t)v + 1] - t.mn[3 * (size_t)v + 1],
+                     ez = (double)t.mx[3 * (size_t)v + 2] - t.mn[3 * (size_t)v + 2];
+        return ex * ey + ey * ez + ez * ex;
+    };
+    auto unionArea = [&](int a, int b) -> double {
+        double e[3];
+        for (int k = 0; k < 3; k++)
+            e[k] = (double)std::max(t.mx[3 * (size_t)a + k], t.mx[3 * (size_t)b + k]) - std::min(t.mn[3 * (size_t)a + k], t.mn[3 * (size_t)b + k]);
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    };
+    auto refit = [&](int v) {  // v and its ancestors: box = union of the children's
+        for (; v >= 0; v = parent[(size_t)v]) {
+            const int l = t.left[(size_t)v], r = t.right[(size_t)v];
+            for (int k = 0; k < 3; k++) {
+                t.mn[3 * (size_t)v + k] = std::min(t.mn[3 * (size_t)l + k], t.mn[3 * (size_t)r + k]);
+                t.mx[3 * (size_t)v + k] = std::max(t.mx[3 * (size_t)l + k], t.mx[3 * (size_t)r + k]);
+            }
+        }
+    };
+    auto total = [&]() { double c = 0.0; for (int i = 0; i < n; i++) if (t.refLeaf[(size_t)i] < 0) c += areaOf(i); return c; };
+    std::vector<int> order((size_t)n);
+    std::priority_queue<std::pair<double, int>> pq;  // (-induced cost, node)
+    double before = total();
+    for (int pass = 0; pass < 8; pass++) {
+        for (int i = 0; i < n; i++) order[(size_t)i] = i;
+        std::vector<double> key((size_t)n);
+        for (int i = 0; i < n; i++) key[(size_t)i] = areaOf(i);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] > key[(size_t)b] || (key[(size_t)a] == key[(size_t)b] && a < b); });
+        for (const int N : order) {
+            const int P = parent[(size_t)N];
+            if (P < 0) continue;                         // the root stays
+            const int G = parent[(size_t)P];
+            if (G < 0 && t.refLeaf[(size_t)(t.left[(size_t)P] == N ? t.right[(size_t)P] : t.left[(size_t)P])] >= 0) continue;  // two nodes left: nothing to choose
+            const int S = t.left[(size_t)P] == N ? t.right[(size_t)P] : t.left[(size_t)P];
+            // take N (and P) out
+            parent[(size_t)S] = G;
+            if (G < 0) root = S;
+            else {
+                if (t.left[(size_t)G] == P) t.left[(size_t)G] = S; else t.right[(size_t)G] = S;
+                refit(G);
+            }
+            // where does N go back?
+            const double aN = areaOf(N);
+            double best = INFINITY;
+            int bestX = S;
+            while (!pq.empty()) pq.pop();
+            pq.push({-0.0, root});
+            while (!pq.empty()) {
+                const double ci = -pq.top().first;
+                const int X = pq.top().second;
+                pq.pop();
+                if (ci + aN >= best) break;
+                const double ct = ci + unionArea(X, N);
+                if (ct < best) { best = ct; bestX = X; }
+                if (t.refLeaf[(size_t)X] < 0) {
+                    const double cc = ct - areaOf(X);
+                    if (cc + aN < best) { pq.push({-cc, t.left[(size_t)X]}); pq.push({-cc, t.right[(size_t)X]}); }
+                }
+            }
+            // P becomes the parent of bestX and N, in bestX's place
+            const int X = bestX, XP = parent[(size_t)X];
+            t.left[(size_t)P] = X; t.right[(size_t)P] = N;
+            parent[(size_t)X] = P; parent[(size_t)N] = P; parent[(size_t)P] = XP;
+            if (XP < 0) root = P;
+            else if (t.left[(size_t)XP] == X) t.left[(size_t)XP] = P; else t.right[(size_t)XP] = P;
+            refit(P);
+        }
+        const double after = total();
+        const bool done = !(after < before * 0.995);
+        before = after;
+        if (done) break;
+    }
+    // renumber: parents before children, root = 0
+    BinTree o;
+    std::vector<int> stack{root}, newId((size_t)n, -1), oldOf;
+    while (!stack.empty()) {
+        const int v = stack.back();
+        stack.pop_back();
+        newId[(size_t)v] = o.add(&t.mn[3 * (size_t)v], &t.mx[3 * (size_t)v], t.refLeaf[(size_t)v]);
+        oldOf.push_back(v);
+        if (t.refLeaf[(size_t)v] < 0) { stack.push_back(t.right[(size_t)v]); stack.push_back(t.left[(size_t)v]); }
+    }
+    for (int i = 0; i < o.size(); i++) {
+        const int v = oldOf[(size_t)i];
+        if (t.refLeaf[(size_t)v] < 0) { o.left[(size_t)i] = newId[(size_t)t.left[(size_t)v]]; o.right[(size_t)i] = newId[(size_t)t.right[(size_t)v]]; }
+    }
+    t = o;
+}
+
+// Builds the 4-wide node array from a binary tree over the reference's leaves -- the reference's own upper tree, or,
+// with `rebuilt`, the hierarchy of rebuild_top: a wide node stands for a binary interior node, its (up
 // to 4) slots are that node's grandchildren, a child that is a leaf taking one slot itself (or, by default, the
 // result of opening the largest box until four slots are taken).  Wide nodes are numbered in the order their
 // parents are opened, largest box first, so the interior children of a node are consecutive (childBase + ordinal)
 // and the nodes met most often come first (they are the ones k_trace_wide keeps in LDS); the leaves get ids of our own, again consecutive per wide
 // node (leafBase + ordinal).  Returns false, leaving the scene on the literal walk, when the input is not the
 // properly nested binary tree the order-free traversal relies on (see kernels_trace.hip) or exceeds its limits.
-static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greedy) {
-    const int n = d->n_nodes;
+static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collapse, const int top) {
+    const bool greedy = collapse == 1, rebuilt = top > 0;  // top: 0 the reference's upper tree, 1 rebuild_top, 2 + optimise_top
     s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear();
     if (!s->planesTame) return false;
-    auto isLeaf = [&](int i) { return d->leaf_count[i] > 0; };
-    std::vector<int> left((size_t)n, -1), right((size_t)n, -1);
-    std::vector<char> seen((size_t)n, 0);
-    seen[0] = 1;
-    for (int i = 0; i < n; i++) {
-        if (isLeaf(i)) continue;
-        const int l = d->id_hit[i];
-        if (!(l > i && l < n)) return false;
-        const int r = d->id_miss[l];
-        if (!(r > l && r < n)) return false;
-        if (seen[l] || seen[r]) return false;  // every node has exactly one parent
-        seen[l] = seen[r] = 1;
-        left[i] = l; right[i] = r;
-        for (const int c : {l, r})
-            for (int a = 0; a < 3; a++)  // exact nesting: the child's box lies inside the parent's
-                if (!(d->node_min[3 * i + a] <= d->node_min[3 * c + a] && d->node_max[3 * c + a] <= d->node_max[3 * i + a])) return false;
+    BinTree bt;
+    {
+        // the premise about the REFERENCE's tree, whichever hierarchy is walked: a proper binary tree, boxes nested
+        const int n = d->n_nodes;
+        std::vector<char> seen((size_t)n, 0);
+        seen[0] = 1;
+        for (int i = 0; i < n; i++) bt.add(&d->node_min[3 * i], &d->node_max[3 * i], d->leaf_count[i] > 0 ? i : -1);
+        for (int i = 0; i < n; i++) {
+            if (d->leaf_count[i] > 0) continue;
+            const int l = d->id_hit[i];
+            if (!(l > i && l < n)) return false;
+            const int r = d->id_miss[l];
+            if (!(r > l && r < n)) return false;
+            if (seen[l] || seen[r]) return false;  // every node has exactly one parent
+            seen[l] = seen[r] = 1;
+            bt.left[(size_t)i] = l; bt.right[(size_t)i] = r;
+            for (const int c : {l, r})
+                for (int a = 0; a < 3; a++)  // exact nesting: the child's box lies inside the parent's
+                    if (!(d->node_min[3 * i + a] <= d->node_min[3 * c + a] && d->node_max[3 * c + a] <= d->node_max[3 * i + a])) return false;
+        }
+        for (int i = 0; i < n; i++)
+            if (!seen[i]) return false;
+        if (rebuilt) {
+            bt = BinTree();
+            rebuild_top(d, bt);
+            if (top > 1) optimise_top(bt);
+        }
     }
-    for (int i = 0; i < n; i++)
-        if (!seen[i]) return false;
+    const int n = bt.size();
+    auto isLeaf = [&](int i) { return bt.refLeaf[(size_t)i] >= 0; };
+    const std::vector<int>& left = bt.left;
+    const std::vector<int>& right = bt.right;
+    const float* node_min = bt.mn.data();
+    const float* node_max = bt.mx.data();
     struct W { int bnode, depth, childBase; };
     std::vector<W> wide;  // in id order
     std::vector<int> slotsOf;  // 4 per wide node: binary node of the slot or -1
     wide.push_back({0, 0, 0});
     int nLeaves = 0;
     auto boxArea = [&](int b) -> double {
-        const double ex = (double)d->node_max[3 * b] - d->node_min[3 * b], ey = (double)d->node_max[3 * b + 1] - d->node_min[3 * b + 1],
-                     ez = (double)d->node_max[3 * b + 2] - d->node_min[3 * b + 2];
+        const double ex = (double)node_max[3 * b] - node_min[3 * b], ey = (double)node_max[3 * b + 1] - node_min[3 * b + 1],
+                     ez = (double)node_max[3 * b + 2] - node_min[3 * b + 2];
         return ex * ey + ey * ez + ez * ex;
     };
     // Nodes are opened largest box first and the children of a node get the next free ids, so that the ids below
     // kWideTopNodes (the ones k_trace_wide keeps in LDS) are the nodes rays meet most often -- on a balanced tree this
     // is breadth-first order -- while the children of a node stay consecutive.
-    std::vector<int> triCount((size_t)n, 0);  // triangles below each binary node (children follow their parent in preorder)
-    for (int i = n - 1; i >= 0; i--) triCount[i] = isLeaf(i) ? d->leaf_count[i] : triCount[left[i]] + triCount[right[i]];
+    std::vector<int> triCount((size_t)n, 0);  // triangles below each binary node (in both trees children have larger ids than their parent)
+    for (int i = n - 1; i >= 0; i--) triCount[i] = isLeaf(i) ? d->leaf_count[bt.refLeaf[(size_t)i]] : triCount[left[i]] + triCount[right[i]];
+    // collapse == 2: the collapse that minimises the expected number of node visits, sum of area(wide node) -- every
+    // visit costs the same whatever it finds, and the leaves' own terms are fixed.  T[v][k] = least cost of standing
+    // for the subtree of v with at most k slots of a wide node: a leaf costs nothing; an interior v either becomes a
+    // wide node itself (one slot; area(v) + the best split of ITS four slots over its children) or, given k >= 2 slots,
+    // is opened in place and shares them out between its children.  Children have larger ids: one backward sweep.
+    std::vector<double> T;
+    std::vector<unsigned char> how;  // per (v, k): 0 = v is a slot itself, i > 0 = opened, i slots to the left child; [v][0]: the split as a wide node
+    if (collapse == 2) {
+        T.assign((size_t)5 * n, 0.0);
+        how.assign((size_t)5 * n, 0);
+        for (int v = n - 1; v >= 0; v--) {
+            if (isLeaf(v)) continue;
+            const int l = left[v], r = right[v];
+            double best = INFINITY;
+            int bi = 1;
+            for (int i = 1; i <= 3; i++) {
+                const double c = T[(size_t)5 * l + i] + T[(size_t)5 * r + 4 - i];
+                if (c < best) { best = c; bi = i; }
+            }
+            const double self = boxArea(v) + best;
+            how[(size_t)5 * v] = (unsigned char)bi;
+            T[(size_t)5 * v + 1] = self;
+            for (int k = 2; k <= 4; k++) {
+                double bk = self;
+                int hk = 0;
+                for (int i = 1; i < k; i++) {
+                    const double c = T[(size_t)5 * l + i] + T[(size_t)5 * r + k - i];
+                    if (c < bk) { bk = c; hk = i; }
+                }
+                T[(size_t)5 * v + k] = bk;
+                how[(size_t)5 * v + k] = (unsigned char)hk;
+            }
+        }
+    }
     std::priority_queue<std::pair<double, int>> open;
     open.push({boxArea(0), 0});
     while (!open.empty()) {
@@ -192,6 +451,20 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
         int sl[4] = {-1, -1, -1, -1}, ns = 0;
         if (isLeaf(b)) {
             sl[ns++] = b;  // a tree that is one leaf: the root wide node has that leaf as its only slot
+        } else if (collapse == 2) {
+            struct Item { int v, k; };
+            Item st[8];
+            int top = 0;
+            const int i0 = how[(size_t)5 * b];
+            st[top++] = {right[b], 4 - i0};
+            st[top++] = {left[b], i0};
+            while (top > 0) {
+                const Item it = st[--top];
+                const int h = (isLeaf(it.v) || it.k == 1) ? 0 : how[(size_t)5 * it.v + it.k];
+                if (h == 0) { sl[ns++] = it.v; continue; }
+                st[top++] = {right[it.v], it.k - h};
+                st[top++] = {left[it.v], h};
+            }
         } else if (greedy) {
             // open the slot with the largest box (the one most rays pierce) until the four slots are taken
             sl[ns++] = left[b]; sl[ns++] = right[b];
@@ -200,9 +473,9 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
                 double best = -1.0;
                 for (int k = 0; k < ns; k++) {
                     if (isLeaf(sl[k])) continue;
-                    const double ex = (double)d->node_max[3 * sl[k]] - d->node_min[3 * sl[k]];
-                    const double ey = (double)d->node_max[3 * sl[k] + 1] - d->node_min[3 * sl[k] + 1];
-                    const double ez = (double)d->node_max[3 * sl[k] + 2] - d->node_min[3 * sl[k] + 2];
+                    const double ex = (double)node_max[3 * sl[k]] - node_min[3 * sl[k]];
+                    const double ey = (double)node_max[3 * sl[k] + 1] - node_min[3 * sl[k] + 1];
+                    const double ez = (double)node_max[3 * sl[k] + 2] - node_min[3 * sl[k] + 2];
                     const double area = ex * ey + ey * ez + ez * ex;
                     if (area > best) { best = area; pick = k; }
                 }
@@ -251,11 +524,11 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
         float lo[3][4], hi[3][4];
         for (int k = 0; k < 4; k++) {
             const int src = sl[k] >= 0 ? sl[k] : sl[0];  // an empty slot repeats slot 0's (tame) box; the masks leave it out
-            for (int a = 0; a < 3; a++) { lo[a][k] = d->node_min[3 * src + a]; hi[a][k] = d->node_max[3 * src + a]; }
+            for (int a = 0; a < 3; a++) { lo[a][k] = node_min[3 * src + a]; hi[a][k] = node_max[3 * src + a]; }
             if (sl[k] < 0) continue;
             if (isLeaf(sl[k])) {
                 leafMask |= 1 << k;
-                const int b = sl[k];
+                const int b = bt.refLeaf[(size_t)sl[k]];  // the reference's leaf: its exact box decides admission
                 s->leafBox.push_back(make_float4(d->node_min[3 * b], d->node_max[3 * b], d->node_min[3 * b + 1], d->node_max[3 * b + 1]));
                 s->leafBox.push_back(make_float4(d->node_min[3 * b + 2], d->node_max[3 * b + 2],
                                                  __builtin_bit_cast(float, d->leaf_first[b]), 0.0f));
@@ -295,6 +568,18 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const bool greed
     }
     if (nextChild != nw) return false;
     s->nWide = nw;
+    if (getenv("MIPT_WIDE_STATS")) {  // expected visits of a random ray that hits the root: sum of box areas over the root's
+        double visits = 0.0, leafOpens = 0.0;
+        int maxDepth = 0;
+        for (int w = 0; w < nw; w++) {
+            visits += boxArea(wide[(size_t)w].bnode);
+            if (wide[(size_t)w].depth > maxDepth) maxDepth = wide[(size_t)w].depth;
+            for (int k = 0; k < 4; k++)
+                if (slotsOf[(size_t)4 * w + k] >= 0 && isLeaf(slotsOf[(size_t)4 * w + k])) leafOpens += boxArea(slotsOf[(size_t)4 * w + k]);
+        }
+        fprintf(stderr, "wide tree (%s): %d nodes, %d leaves, depth %d, expected visits %.3f, expected leaf opens %.3f\n",
+                top == 2 ? "optimised top" : top == 1 ? "rebuilt top" : "reference top", nw, nLeaves, maxDepth, visits / boxArea(0), leafOpens / boxArea(0));
+    }
     return true;
 }
 
@@ -582,7 +867,17 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
             if (!cv) { return fail(MIPT_ERR_INVALID, "tri_index entry not owned by any leaf"); }
         // slots by largest box first; a tree that this makes deeper than the kernel's stacks falls back to plain grandchildren
         const char* collapse = getenv("MIPT_WIDE_COLLAPSE");  // "pairs": grandchildren only (for comparisons)
-        s->wideOk = (!(collapse && !strcmp(collapse, "pairs")) && build_wide(d, s, true)) || build_wide(d, s, false);
+        const char* topEnv = getenv("MIPT_WIDE_TOP");  // reference | rebuilt | optimised (default): the hierarchy above the leaves
+        int mode = 2, top = 2;  // MIPT_WIDE_COLLAPSE = pairs | greedy | optimal (default)
+        if (collapse && !strcmp(collapse, "pairs")) mode = 0;
+        else if (collapse && !strcmp(collapse, "greedy")) mode = 1;
+        if (topEnv && !strcmp(topEnv, "reference")) top = 0;
+        else if (topEnv && !strcmp(topEnv, "rebuilt")) top = 1;
+        // the best tree first; the only way one fails is by being deeper than the kernel's stacks, then the next best is
+        // tried, down to the plain grandchildren of the reference's tree
+        s->wideOk = false;
+        for (int m = mode; m >= 0 && !s->wideOk; m--)
+            for (int t = (m > 0 ? top : 0); t >= 0 && !s->wideOk; t--) s->wideOk = build_wide(d, s, m, t);
         if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear(); s->nWide = 0; }
         if (is_binary_tree(d)) {  // right child = where the left subtree's walk exits; independent of the wide tree and of the planes
             s->nodeRight.assign((size_t)n, 0);
