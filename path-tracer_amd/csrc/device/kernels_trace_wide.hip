@@ -37,7 +37,7 @@ namespace ptd {
 #define PT_TUNE_WIDE_WAVES 4
 #endif
 #ifndef PT_TUNE_WIDE_BURST
-#define PT_TUNE_WIDE_BURST 12         // visits between two votes, closest hit (r2, fp16 nodes: 6: 5.42 ms per bench launch, 8: 5.25, 12: 5.07, 16: 5.09, 24: 5.35)
+#define PT_TUNE_WIDE_BURST 16         // visits between two votes, closest hit (r2, fp16 nodes: 6: 5.42 ms per bench launch, 8: 5.25, 12: 5.07, 16: 5.09, 24: 5.35; with the rebuilt hierarchy: 8: 4.72, 12: 4.56, 16: 4.53, 20: 4.64)
 #endif
 #ifndef PT_TUNE_WIDE_STATIC_SHIFT
 #define PT_TUNE_WIDE_STATIC_SHIFT 2   // the static first chunks cover 1 - 2^-shift of the queue
@@ -82,7 +82,29 @@ namespace ptd {
 #ifndef PT_TUNE_WIDE_STUCK_ANYHIT
 #define PT_TUNE_WIDE_STUCK_ANYHIT 16
 #endif
-constexpr int kWideBlock = PT_TUNE_WIDE_BLOCK;
+// The any-hit instantiation runs FIVE wavefronts per SIMD: 256-thread blocks (one wavefront per SIMD), five per CU, each
+// with its own 16 KB of stacks and a 216-node top of the tree (30.5 KB of LDS per block; 32.7 KB each did not fit five).
+// Measured with the rebuilt hierarchy: 1.375 -> 1.28 ms per any-hit bench launch.  The closest-hit instantiation
+// needs 101 VGPRs (5 wavefronts allow 96: three spilled registers) and gains 1.3 % at equal LDS but loses 2.7 % against
+// its big-LDS configuration, so it stays at one 1024-thread block per CU, 4 wavefronts per SIMD.
+#ifndef PT_TUNE_WIDE_BLOCK_ANYHIT
+#define PT_TUNE_WIDE_BLOCK_ANYHIT 256
+#endif
+#ifndef PT_TUNE_WIDE_WAVES_ANYHIT
+#define PT_TUNE_WIDE_WAVES_ANYHIT 5
+#endif
+#ifndef PT_TUNE_WIDE_PER_CU_ANYHIT
+#define PT_TUNE_WIDE_PER_CU_ANYHIT 5
+#endif
+#ifndef PT_TUNE_WIDE_TOP_ANYHIT
+#define PT_TUNE_WIDE_TOP_ANYHIT 216
+#endif
+template <bool ANYHIT> struct WideCfg {
+    static constexpr int kBlock = ANYHIT ? PT_TUNE_WIDE_BLOCK_ANYHIT : PT_TUNE_WIDE_BLOCK;
+    static constexpr int kWaves = ANYHIT ? PT_TUNE_WIDE_WAVES_ANYHIT : PT_TUNE_WIDE_WAVES;
+    static constexpr int kPerCU = ANYHIT ? PT_TUNE_WIDE_PER_CU_ANYHIT : kWideBlocksPerCU;
+    static constexpr int kTop = ANYHIT ? (PT_TUNE_WIDE_TOP_ANYHIT < kWideTopNodes ? PT_TUNE_WIDE_TOP_ANYHIT : kWideTopNodes) : kWideTopNodes;
+};
 #ifndef PT_TUNE_WIDE_GROUPS
 #define PT_TUNE_WIDE_GROUPS 4
 #endif
@@ -202,19 +224,20 @@ __device__ __forceinline__ int group_take(unsigned& e) {  // removes the lowest 
 #ifndef PT_DIAG_UTIL
 #define PT_DIAG_UTIL 0  // diagnostic builds only: 1 / 2 turn the counters into lanes-active / lanes-issued of the visit / leaf phase
 #endif
-#define PT_WIDE_ATTR __attribute__((amdgpu_waves_per_eu(PT_TUNE_WIDE_WAVES, PT_TUNE_WIDE_WAVES)))
+#define PT_WIDE_ATTR __attribute__((amdgpu_waves_per_eu(WideCfg<ANYHIT>::kWaves, WideCfg<ANYHIT>::kWaves)))
 
 template <bool ANYHIT, bool COUNT>
-__global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
+__global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_wide(
     DevScene s, const float4* __restrict__ rays, const int* __restrict__ index, const int* __restrict__ target,
     QueueView q, unsigned* __restrict__ cursor, float4* __restrict__ hits, unsigned char* __restrict__ occ,
     unsigned long long* __restrict__ counters, unsigned* __restrict__ slowCount, int* __restrict__ slowList) {
-    __shared__ float4 top[kWideNodeF4 * kWideTopNodes];
-    __shared__ unsigned stackLds[kWideMaxDepth * kWideBlock];  // entry d of lane t at [d * kWideBlock + t]
+    constexpr int kBlk = WideCfg<ANYHIT>::kBlock;  // threads per block; shadows nothing: the launchers use the same WideCfg
+    __shared__ float4 top[kWideNodeF4 * WideCfg<ANYHIT>::kTop];
+    __shared__ unsigned stackLds[kWideMaxDepth * kBlk];  // entry d of lane t at [d * kBlk + t]
     __shared__ unsigned prefix[kShards + 1];
     const int lane = threadIdx.x & 63;
-    const int nTop = s.nWideTop;
-    for (int i = threadIdx.x; i < kWideNodeF4 * nTop; i += kWideBlock)  // packed in LDS, kWideNodeStrideF4 apart in the arena
+    const int nTop = s.nWideTop < WideCfg<ANYHIT>::kTop ? s.nWideTop : WideCfg<ANYHIT>::kTop;
+    for (int i = threadIdx.x; i < kWideNodeF4 * nTop; i += kBlk)  // packed in LDS, kWideNodeStrideF4 apart in the arena
         top[i] = s.wnodes[(i / kWideNodeF4) * kWideNodeStrideF4 + i % kWideNodeF4];
     if (q.counts) {
         if (threadIdx.x < 64) {
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     int w = -1;             // next wide node to visit (-1: the walk is over)
     unsigned tos = 0;       // top of the stack of interior groups (0: none); older entries in stack[0..sp)
     __attribute__((address_space(3))) unsigned* stack = (__attribute__((address_space(3))) unsigned*)stackLds + threadIdx.x;
-    int sp = 0;  // in units of kWideBlock entries
+    int sp = 0;  // in units of kBlk entries
     // leaf groups still to be opened (LIFO, g[0] on top; order is free) and the open leaf's triangle cursor
     int groups = 0;
     unsigned g[kWideGroups] = {};  // compile-time indices only: registers
@@ -281,8 +304,8 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     // ended with 4,096 more atomics that only said "empty": 2 x 4,096 x 12 ns = the 100 us such a launch took for 8 us
     // of instructions (SQ_INSTS_VALU / SQ_WAVE_CYCLES of the launch).  A 1 M-ray launch spent 16,384 atomics (all
     // chunks at the 64-ray floor) = 0.2 ms of its 0.34 ms the same way.
-    const unsigned nWaves = gridDim.x * (unsigned)(kWideBlock / 64);
-    const unsigned gw = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)(kWideBlock / 64) + (threadIdx.x >> 6)));
+    const unsigned nWaves = gridDim.x * (unsigned)(kBlk / 64);
+    const unsigned gw = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)(kBlk / 64) + (threadIdx.x >> 6)));
     unsigned c0 = ((total - (total >> PT_TUNE_WIDE_STATIC_SHIFT)) / nWaves) & ~63u;
     c0 = c0 < 64u ? 64u : (c0 > 1024u ? 1024u : c0);
     const unsigned long long staticAll = (unsigned long long)nWaves * c0;
@@ -480,7 +503,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     ++groups;
                 }
                 if (ih != 0) {  // the hit children go on top of the stack as one entry
-                    if (tos != 0u) { stack[sp] = tos; sp += kWideBlock; }
+                    if (tos != 0u) { stack[sp] = tos; sp += kBlk; }
                     tos = pack_group(f2i(meta.x), imask, ih);
                 }
                 w = -1;
@@ -488,7 +511,7 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
                     w = group_take(tos);
                     if ((tos & 15u) == 0u) {
                         tos = 0u;
-                        if (sp > 0) { sp -= kWideBlock; tos = stack[sp]; }
+                        if (sp > 0) { sp -= kBlk; tos = stack[sp]; }
                     }
                 }
             }
@@ -595,33 +618,34 @@ __global__ __launch_bounds__(kWideBlock) PT_WIDE_ATTR void k_trace_wide(
     }
 }
 
+template <bool ANYHIT>
 static inline unsigned wide_grid(size_t nMax) {
-    size_t g = (nMax + kWideBlock - 1) / kWideBlock;
+    size_t g = (nMax + WideCfg<ANYHIT>::kBlock - 1) / WideCfg<ANYHIT>::kBlock;
     if (g < 1) g = 1;
-    const size_t cap = (size_t)256 * kWideBlocksPerCU;  // as many blocks as fit the CUs' LDS at once
+    const size_t cap = (size_t)256 * WideCfg<ANYHIT>::kPerCU;  // as many blocks as fit the CUs' LDS at once
     if (g > cap) g = cap;
     return (unsigned)g;
 }
 void launch_trace_wide_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
                                unsigned* cursor, float4* hits, unsigned long long* counters, unsigned* slowCount,
                                int* slowList) {
-    const unsigned g = wide_grid(q.space);
+    const unsigned g = wide_grid<false>(q.space);
     if (counters)
-        hipLaunchKernelGGL((k_trace_wide<false, true>), dim3(g), dim3(kWideBlock), 0, st, s, rays, index, nullptr, q, cursor,
+        hipLaunchKernelGGL((k_trace_wide<false, true>), dim3(g), dim3(WideCfg<false>::kBlock), 0, st, s, rays, index, nullptr, q, cursor,
                            hits, nullptr, counters, slowCount, slowList);
     else
-        hipLaunchKernelGGL((k_trace_wide<false, false>), dim3(g), dim3(kWideBlock), 0, st, s, rays, index, nullptr, q, cursor,
+        hipLaunchKernelGGL((k_trace_wide<false, false>), dim3(g), dim3(WideCfg<false>::kBlock), 0, st, s, rays, index, nullptr, q, cursor,
                            hits, nullptr, counters, slowCount, slowList);
 }
 void launch_trace_wide_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
                                 unsigned* cursor, unsigned char* occ, unsigned long long* counters, unsigned* slowCount,
                                 int* slowList) {
-    const unsigned g = wide_grid(q.space);
+    const unsigned g = wide_grid<true>(q.space);
     if (counters)
-        hipLaunchKernelGGL((k_trace_wide<true, true>), dim3(g), dim3(kWideBlock), 0, st, s, rays, nullptr, target, q, cursor,
+        hipLaunchKernelGGL((k_trace_wide<true, true>), dim3(g), dim3(WideCfg<true>::kBlock), 0, st, s, rays, nullptr, target, q, cursor,
                            nullptr, occ, counters, slowCount, slowList);
     else
-        hipLaunchKernelGGL((k_trace_wide<true, false>), dim3(g), dim3(kWideBlock), 0, st, s, rays, nullptr, target, q, cursor,
+        hipLaunchKernelGGL((k_trace_wide<true, false>), dim3(g), dim3(WideCfg<true>::kBlock), 0, st, s, rays, nullptr, target, q, cursor,
                            nullptr, occ, counters, slowCount, slowList);
 }
 
