@@ -203,7 +203,7 @@ static void rebuild_top(const mipt_scene_desc* d, BinTree& t) {
         jobs.pop_back();
         const int cnt = j.end - j.begin;
         double bestCost = INFINITY;
-        int bestSplit = -1;
+        int bestSplit = -1, bestAxis = -1;
         for (int axis = 0; axis < 3; axis++) {
             tmp.assign(idx.begin() + j.begin, idx.begin() + j.end);
             std::sort(tmp.begin(), tmp.end(), [&](int x, int y) {
@@ -224,8 +224,9 @@ static void rebuild_top(const mipt_scene_desc* d, BinTree& t) {
                 grow(lo, hi, leaves[(size_t)tmp[(size_t)k - 1]]);
                 wl += leaves[(size_t)tmp[(size_t)k - 1]].w;
                 const double cost = area(lo, hi) * (double)wl + rightArea[(size_t)k] * (double)rightW[(size_t)k];
-                if (cost < bestCost) { bestCost = cost; bestSplit = k; best = tmp; }
+                if (cost < bestCost) { bestCost = cost; bestSplit = k; bestAxis = axis; }
             }
+            if (bestAxis == axis) best.swap(tmp);  // keep the order of the axis that holds the best split so far
         }
         if (bestSplit < 0) { bestSplit = cnt / 2; best.assign(idx.begin() + j.begin, idx.begin() + j.end); }  // NaN-free input never gets here
         std::copy(best.begin(), best.end(), idx.begin() + j.begin);
