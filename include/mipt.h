@@ -260,6 +260,12 @@ int mipt_scene_exact_reciprocal(const mipt_scene*);
  * not a binary tree, deeper than 32 levels) and every ray takes the literal threaded walk of
  * StacklessBVH::intersect (C:1661-1683).  Results are bit-identical either way.  No counterpart in the reference. */
 int mipt_scene_wide_nodes(const mipt_scene*);
+/* Host-side check (no GPU) of what the order-free traversal rests on: the 4-wide tree -- a hierarchy of the library's
+ * own over the reference's LEAVES, see DESIGN.md 4 -- reaches every leaf exactly once, and every slot's stored box
+ * contains everything stored below it, down to the leaf's exact box.  MIPT_OK (with the number of leaves and the
+ * depth of the wide tree, 0 and 0 for a scene on the literal walk) or MIPT_ERR_INVALID with the reason in
+ * mipt_last_error().  No counterpart in the reference. */
+int mipt_scene_selfcheck_wide(const mipt_scene*, int* leaves_out, int* depth_out);
 
 /* One context per GPU: uploads the scene as ONE hipMalloc'd arena of flat
  * SoA sections (replaces create(&deviceScene, globalScene), G:3181).  A

@@ -78,7 +78,7 @@ SYMBOLS = [
     "mipt_bvh_node_min", "mipt_bvh_node_max", "mipt_bvh_id_hit", "mipt_bvh_id_miss", "mipt_bvh_leaf_first",
     "mipt_bvh_leaf_count", "mipt_bvh_id_left", "mipt_bvh_id_right", "mipt_bvh_id_parent", "mipt_bvh_id_sibling",
     "mipt_bvh_tri_index", "mipt_bvh_destroy",
-    "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_destroy", "mipt_scene_exact_reciprocal", "mipt_scene_wide_nodes",
+    "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_destroy", "mipt_scene_exact_reciprocal", "mipt_scene_wide_nodes", "mipt_scene_selfcheck_wide",
     "mipt_context_create", "mipt_context_destroy", "mipt_context_arena_bytes",
     "mipt_trace", "mipt_trace_device", "mipt_trace_device_noalloc", "mipt_occluded", "mipt_eye_rays", "mipt_background",
     "mipt_selftest_fast_division", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
@@ -153,6 +153,8 @@ def lib():
     L.mipt_scene_exact_reciprocal.restype = C.c_int32
     L.mipt_scene_wide_nodes.argtypes = [vp]
     L.mipt_scene_wide_nodes.restype = C.c_int32
+    L.mipt_scene_selfcheck_wide.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.mipt_scene_selfcheck_wide.restype = C.c_int32
     L.mipt_scene_desc_fill.argtypes = [vp, vp, vp, C.POINTER(Light), C.c_int32, C.POINTER(SceneDesc)]
     L.mipt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
     L.mipt_context_create.argtypes = [vp, C.c_int, vp, C.POINTER(vp)]
@@ -485,6 +487,13 @@ class Scene:
     def wide_nodes(self):
         """nodes of the 4-wide tree of the order-free traversal kernel; 0 = this scene takes the literal walk"""
         return int(lib().mipt_scene_wide_nodes(self.h))
+
+    def selfcheck_wide(self):
+        """(leaves, depth) of the 4-wide tree after checking that it reaches every leaf once and that every stored box
+        contains what lies below it (mipt_scene_selfcheck_wide; host only); raises MiptError otherwise"""
+        leaves, depth = C.c_int32(), C.c_int32()
+        check(lib().mipt_scene_selfcheck_wide(self.h, C.byref(leaves), C.byref(depth)))
+        return leaves.value, depth.value
 
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:

@@ -948,6 +948,86 @@ void mipt_scene_destroy(mipt_scene* s) { delete s; }
 int mipt_scene_exact_reciprocal(const mipt_scene* s) { return (s && s->planesTame) ? 1 : 0; }
 int mipt_scene_wide_nodes(const mipt_scene* s) { return (s && s->wideOk) ? s->nWide : 0; }
 
+// What the order-free traversal rests on, checked on the finished arrays (host only, no GPU): the wide tree reaches
+// every leaf of the scene exactly once, every slot's STORED box (fp16, rounded outwards) contains the stored boxes of
+// the node below it resp. the exact box of its leaf, and every leaf record points at a distinct first triangle.
+int mipt_scene_selfcheck_wide(const mipt_scene* s, int* leaves_out, int* depth_out) {
+    return guarded("mipt_scene_selfcheck_wide", [&]() -> int {
+    if (!s) return fail(MIPT_ERR_INVALID, "mipt_scene_selfcheck_wide: null argument");
+    if (leaves_out) *leaves_out = 0;
+    if (depth_out) *depth_out = 0;
+    if (!s->wideOk) return MIPT_OK;  // nothing to check: every ray takes the literal walk
+#if !PT_WIDE_HALF
+    return fail(MIPT_ERR_INVALID, "mipt_scene_selfcheck_wide: built without the fp16 node layout");
+#else
+    const int nw = s->nWide, nLeaves = (int)(s->leafBox.size() / 2);
+    std::vector<char> nodeSeen((size_t)nw, 0), leafSeen((size_t)nLeaves, 0);
+    struct Box { float lo[3], hi[3]; };
+    auto slotBox = [&](int w, int k) {
+        Box b;
+        for (int a = 0; a < 3; a++) {
+            unsigned short h[8];
+            memcpy(h, &s->wnodes[(size_t)ptd::kWideNodeStrideF4 * w + a], 16);
+            b.lo[a] = half_value(h[k]); b.hi[a] = half_value(h[4 + k]);
+        }
+        return b;
+    };
+    auto inside = [](const Box& in, const Box& out) {
+        for (int a = 0; a < 3; a++)
+            if (!(out.lo[a] <= in.lo[a] && in.hi[a] <= out.hi[a])) return false;
+        return true;
+    };
+    struct Item { int w, depth; };
+    std::vector<Item> stack{{0, 0}};
+    int maxDepth = 0, reached = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        if (it.w < 0 || it.w >= nw || nodeSeen[(size_t)it.w]) return fail(MIPT_ERR_INVALID, "wide tree: a node is out of range or reached twice");
+        nodeSeen[(size_t)it.w] = 1;
+        if (it.depth > maxDepth) maxDepth = it.depth;
+        const float4 meta = s->wnodes[(size_t)ptd::kWideNodeStrideF4 * it.w + 3];
+        const int childBase = __builtin_bit_cast(int, meta.x), leafBase = __builtin_bit_cast(int, meta.y), masks = __builtin_bit_cast(int, meta.z);
+        const int imask = masks & 15, lmask = (masks >> 4) & 15;
+        if ((imask & lmask) != 0 || (imask | lmask) == 0) return fail(MIPT_ERR_INVALID, "wide tree: bad slot masks");
+        int ni = 0, nl = 0;
+        for (int k = 0; k < 4; k++) {
+            const Box sb = slotBox(it.w, k);
+            if (imask & (1 << k)) {
+                const int c = childBase + ni++;
+                if (c <= it.w || c >= nw) return fail(MIPT_ERR_INVALID, "wide tree: a child id does not point forward");
+                const float4 cm = s->wnodes[(size_t)ptd::kWideNodeStrideF4 * c + 3];
+                const int cmask = __builtin_bit_cast(int, cm.z);
+                for (int j = 0; j < 4; j++)
+                    if (((cmask | (cmask >> 4)) & 15) & (1 << j))
+                        if (!inside(slotBox(c, j), sb)) return fail(MIPT_ERR_INVALID, "wide tree: a slot's box does not contain a box of the node below it");
+                stack.push_back({c, it.depth + 1});
+            } else if (lmask & (1 << k)) {
+                const int l = leafBase + nl++;
+                if (l < 0 || l >= nLeaves || leafSeen[(size_t)l]) return fail(MIPT_ERR_INVALID, "wide tree: a leaf is out of range or reached twice");
+                leafSeen[(size_t)l] = 1;
+                reached++;
+                const float4 b0 = s->leafBox[(size_t)2 * l], b1 = s->leafBox[(size_t)2 * l + 1];
+                const Box lb{{b0.x, b0.z, b1.x}, {b0.y, b0.w, b1.y}};
+                if (!inside(lb, sb)) return fail(MIPT_ERR_INVALID, "wide tree: a slot's box does not contain its leaf's exact box");
+            }
+        }
+    }
+    if (reached != nLeaves) return fail(MIPT_ERR_INVALID, "wide tree: not every leaf is reached");
+    for (int w = 0; w < nw; w++)
+        if (!nodeSeen[(size_t)w]) return fail(MIPT_ERR_INVALID, "wide tree: an unreachable node");
+    std::vector<int> firsts;
+    for (int l = 0; l < nLeaves; l++) firsts.push_back(__builtin_bit_cast(int, s->leafBox[(size_t)2 * l + 1].z));
+    std::sort(firsts.begin(), firsts.end());
+    for (size_t i = 1; i < firsts.size(); i++)
+        if (firsts[i] == firsts[i - 1]) return fail(MIPT_ERR_INVALID, "wide tree: two leaves share their first triangle");
+    if (leaves_out) *leaves_out = nLeaves;
+    if (depth_out) *depth_out = maxDepth;
+    return MIPT_OK;
+#endif
+    });
+}
+
 int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx** out) {
     return guarded("mipt_context_create", [&]() -> int {
     if (!s || !out) return fail(MIPT_ERR_INVALID, "mipt_context_create: null argument");

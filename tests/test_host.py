@@ -368,3 +368,29 @@ def test_hdr_header_larger_than_file_is_refused(B, tmp_path):
     p.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2000000000 +X 2000000000\n" + bytes(64))
     with pytest.raises(B.MiptError):
         B.Image.load(str(p))
+
+
+@pytest.mark.parametrize("top", ["optimised", "rebuilt", "reference"])
+@pytest.mark.parametrize("name", ["cornellbox", "teapot-glass", "testObj", "sponza", "single"])
+def test_wide_tree_over_the_references_leaves(B, sf, name, top, monkeypatch):
+    """The order-free traversal walks a hierarchy of the library's own over the REFERENCE's leaves (an all-axes SAH build
+    over the leaf boxes, insertion-optimised, collapsed four wide; MIPT_WIDE_TOP selects the plainer ones).  Whatever
+    the hierarchy, the hits are the reference's only if it reaches every reference leaf exactly once and every stored
+    (fp16, outward-rounded) box contains everything below it down to the leaf's exact box: mipt_scene_selfcheck_wide
+    checks exactly that on the arrays the GPU will read."""
+    monkeypatch.setenv("MIPT_WIDE_TOP", top)
+    if name == "single":
+        mesh = B.Mesh.single_triangle() if hasattr(B.Mesh, "single_triangle") else None
+        if mesh is None:
+            pytest.skip("no single-triangle helper")
+        scene = B.Scene(mesh)
+        n_leaves_ref = 1
+    else:
+        arrays = sf.sponza_standin(1) if name == "sponza" else sf.load_scene_arrays(name)
+        scene = sf.product_scene_from_mesh_arrays(*arrays, lights=sf.DEFAULT_LIGHT)
+        n_leaves_ref = None
+    assert scene.wide_nodes > 0
+    leaves, depth = scene.selfcheck_wide()
+    assert leaves > 0 and 0 <= depth < 16
+    if n_leaves_ref is not None:
+        assert leaves == n_leaves_ref
