@@ -374,3 +374,40 @@ def test_rays_through_vertices_and_the_exact_walk_kernels_on_ordinary_rays(B, ob
                 np.array_equal(bits(got[2]), bits(ref[2])), (name, n, hand_back)
             assert np.array_equal(ctx.occluded(o, d, 1e-4, 2.0), oref), (name, n, hand_back)
         monkeypatch.delenv("MIPT_HAND_BACK_ALL")
+
+
+@pytest.mark.parametrize("name", ["teapot-glass", "testObj", "sponza"])
+def test_every_hierarchy_over_the_references_leaves_gives_the_oracles_hits(B, ob, sf, name, monkeypatch):
+    """k_trace_wide walks a hierarchy of the library's own over the reference's leaves (default: all-axes SAH over the
+    leaf boxes, insertion-optimised, collapsed four wide with the least expected visits).  The hits must not depend on
+    which hierarchy that is: MIPT_WIDE_TOP = reference | rebuilt | optimised and MIPT_WIDE_COLLAPSE = pairs | greedy |
+    optimal all have to return the oracle's bits (threaded walk over the reference's own tree) on primary and on
+    incoherent rays, closest hit and any hit -- and the default must visit fewer nodes than round 1's tree did."""
+    arrays = sf.sponza_standin(1) if name == "sponza" else sf.load_scene_arrays(name)
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+    pos = np.asarray(arrays[0], np.float32).reshape(-1, 3)
+    lo, hi = pos.min(0), pos.max(0)
+    rng = np.random.default_rng(11)
+    n = 40000
+    o = (lo + (hi - lo) * rng.uniform(0.02, 0.98, (n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    ref = orc.intersect(o, d)
+    ref_occ = orc.occluded(o, d, 1e-4, 0.6 * float(np.linalg.norm(hi - lo)))
+    visits = {}
+    for top, collapse in (("optimised", "optimal"), ("rebuilt", "optimal"), ("rebuilt", "greedy"), ("reference", "optimal"),
+                          ("reference", "greedy"), ("reference", "pairs")):
+        monkeypatch.setenv("MIPT_WIDE_TOP", top)
+        monkeypatch.setenv("MIPT_WIDE_COLLAPSE", collapse)
+        scene = sf.product_scene_from_mesh_arrays(*arrays)
+        assert scene.wide_nodes > 0
+        scene.selfcheck_wide()
+        ctx = B.Context(scene, device=0)
+        ctx.reset_stats(); ctx.set_counting(True)
+        got = ctx.trace(o, d)
+        visits[(top, collapse)] = ctx.stats()["node_visits_closest"]
+        ctx.set_counting(False)
+        assert np.array_equal(got[0], ref[0]), (top, collapse, "triangle ids")
+        assert np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(bits(got[2]), bits(ref[2])), (top, collapse)
+        assert np.array_equal(ctx.occluded(o, d, 1e-4, 0.6 * float(np.linalg.norm(hi - lo))), ref_occ), (top, collapse, "any hit")
+    assert visits[("optimised", "optimal")] < visits[("reference", "greedy")]
