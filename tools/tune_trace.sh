@@ -16,9 +16,10 @@ if [ "$1" = build ]; then
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src/device/kernels_trace.hip -o $out/kt_$name.o
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src/device/kernels_trace_wide.hip -o $out/kw_$name.o
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src/api/api_device.hip -o $out/api_$name.o   # kTopNodes / kWideTopNodes are used on the host side too
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libmipt_$name.so $out/kt_$name.o $out/kw_$name.o $src/device/kernels_integrate.o $src/device/kernels_trace_bittrail.o $src/device/kernels_tiles.o \
+    /opt/rocm/bin/hipcc $FLAGS $defs -c $src/device/kernels_integrate.hip -o $out/ki_$name.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/libmipt_$name.so $out/kt_$name.o $out/kw_$name.o $out/ki_$name.o $src/device/kernels_trace_bittrail.o $src/device/kernels_tiles.o \
         $out/api_$name.o $src/api/api_node.o $src/api/api_host.o $src/host/obj_loader.o $src/host/bvh_build.o $src/host/image_io.o $src/host/scene_cache.o -lz -ldl -lpthread
-    rm -f $out/kt_$name.o $out/kw_$name.o $out/api_$name.o
+    rm -f $out/kt_$name.o $out/kw_$name.o $out/api_$name.o $out/ki_$name.o
     echo "built $name ($defs)"
   done
 elif [ "$1" = benchall ]; then
