@@ -357,6 +357,7 @@ static void optimise_top(BinTree& t) {
 // node (leafBase + ordinal).  Returns false, leaving the scene on the literal walk, when the input is not the
 // properly nested binary tree the order-free traversal relies on (see kernels_trace.hip) or exceeds its limits.
 static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collapse, const int top) {
+    constexpr int K = ptd::kWideK;  // slots per wide node
     const bool greedy = collapse == 1, rebuilt = top > 0;  // top: 0 the reference's upper tree, 1 rebuild_top, 2 + optimise_top
     s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear();
     if (!s->planesTame) return false;
@@ -417,29 +418,29 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
     std::vector<double> T;
     std::vector<unsigned char> how;  // per (v, k): 0 = v is a slot itself, i > 0 = opened, i slots to the left child; [v][0]: the split as a wide node
     if (collapse == 2) {
-        T.assign((size_t)5 * n, 0.0);
-        how.assign((size_t)5 * n, 0);
+        T.assign((size_t)(K + 1) * n, 0.0);
+        how.assign((size_t)(K + 1) * n, 0);
         for (int v = n - 1; v >= 0; v--) {
             if (isLeaf(v)) continue;
             const int l = left[v], r = right[v];
             double best = INFINITY;
             int bi = 1;
-            for (int i = 1; i <= 3; i++) {
-                const double c = T[(size_t)5 * l + i] + T[(size_t)5 * r + 4 - i];
+            for (int i = 1; i < K; i++) {
+                const double c = T[(size_t)(K + 1) * l + i] + T[(size_t)(K + 1) * r + K - i];
                 if (c < best) { best = c; bi = i; }
             }
             const double self = boxArea(v) + best;
-            how[(size_t)5 * v] = (unsigned char)bi;
-            T[(size_t)5 * v + 1] = self;
-            for (int k = 2; k <= 4; k++) {
+            how[(size_t)(K + 1) * v] = (unsigned char)bi;
+            T[(size_t)(K + 1) * v + 1] = self;
+            for (int k = 2; k <= K; k++) {
                 double bk = self;
                 int hk = 0;
                 for (int i = 1; i < k; i++) {
-                    const double c = T[(size_t)5 * l + i] + T[(size_t)5 * r + k - i];
+                    const double c = T[(size_t)(K + 1) * l + i] + T[(size_t)(K + 1) * r + k - i];
                     if (c < bk) { bk = c; hk = i; }
                 }
-                T[(size_t)5 * v + k] = bk;
-                how[(size_t)5 * v + k] = (unsigned char)hk;
+                T[(size_t)(K + 1) * v + k] = bk;
+                how[(size_t)(K + 1) * v + k] = (unsigned char)hk;
             }
         }
     }
@@ -449,19 +450,20 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
         const size_t w = (size_t)open.top().second;
         open.pop();
         const int b = wide[w].bnode;
-        int sl[4] = {-1, -1, -1, -1}, ns = 0;
+        int sl[K], ns = 0;
+        for (int k = 0; k < K; k++) sl[k] = -1;
         if (isLeaf(b)) {
             sl[ns++] = b;  // a tree that is one leaf: the root wide node has that leaf as its only slot
         } else if (collapse == 2) {
             struct Item { int v, k; };
-            Item st[8];
+            Item st[2 * K];
             int top = 0;
-            const int i0 = how[(size_t)5 * b];
-            st[top++] = {right[b], 4 - i0};
+            const int i0 = how[(size_t)(K + 1) * b];
+            st[top++] = {right[b], K - i0};
             st[top++] = {left[b], i0};
             while (top > 0) {
                 const Item it = st[--top];
-                const int h = (isLeaf(it.v) || it.k == 1) ? 0 : how[(size_t)5 * it.v + it.k];
+                const int h = (isLeaf(it.v) || it.k == 1) ? 0 : how[(size_t)(K + 1) * it.v + it.k];
                 if (h == 0) { sl[ns++] = it.v; continue; }
                 st[top++] = {right[it.v], it.k - h};
                 st[top++] = {left[it.v], h};
@@ -469,7 +471,7 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
         } else if (greedy) {
             // open the slot with the largest box (the one most rays pierce) until the four slots are taken
             sl[ns++] = left[b]; sl[ns++] = right[b];
-            while (ns < 4) {
+            while (ns < K) {
                 int pick = -1;
                 double best = -1.0;
                 for (int k = 0; k < ns; k++) {
@@ -502,10 +504,11 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
             else if (mode == "small") std::stable_sort(sl, sl + ns, [&](int a, int b) { return boxArea(a) < boxArea(b); });
             else if (mode == "count") std::stable_sort(sl, sl + ns, [&](int a, int b) { return triCount[a] > triCount[b]; });
         }
-        if (slotsOf.size() < 4 * wide.size()) slotsOf.resize(4 * wide.size(), -1);
+        if (K == 8) std::stable_partition(sl, sl + ns, [&](int a) { return !isLeaf(a); });  // eight-slot records: interior slots first (device_scene.hpp)
+        if (slotsOf.size() < (size_t)K * wide.size()) slotsOf.resize((size_t)K * wide.size(), -1);
         wide[w].childBase = (int)wide.size();
-        for (int k = 0; k < 4; k++) {
-            slotsOf[4 * w + k] = sl[k];
+        for (int k = 0; k < K; k++) {
+            slotsOf[(size_t)K * w + k] = sl[k];
             if (sl[k] >= 0 && !isLeaf(sl[k])) {
                 open.push({boxArea(sl[k]), (int)wide.size()});
                 wide.push_back({sl[k], wide[w].depth + 1, 0});
@@ -515,15 +518,15 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
         if (wide.size() >= ((size_t)1 << 22)) return false;
     }
     const int nw = (int)wide.size();
-    slotsOf.resize((size_t)4 * nw, -1);
+    slotsOf.resize((size_t)K * nw, -1);
     s->wnodes.assign((size_t)ptd::kWideNodeStrideF4 * nw, make_float4(0, 0, 0, 0));
     // second pass: records (children of wide node w start at its childBase, in the order the first pass appended them)
     int nextChild = 1;
     for (int w = 0; w < nw; w++) {
-        const int* sl = &slotsOf[(size_t)4 * w];
+        const int* sl = &slotsOf[(size_t)K * w];
         int interiorMask = 0, leafMask = 0, childBase = wide[w].childBase, leafBase = nLeaves;
-        float lo[3][4], hi[3][4];
-        for (int k = 0; k < 4; k++) {
+        float lo[3][K], hi[3][K];
+        for (int k = 0; k < K; k++) {
             const int src = sl[k] >= 0 ? sl[k] : sl[0];  // an empty slot repeats slot 0's (tame) box; the masks leave it out
             for (int a = 0; a < 3; a++) { lo[a][k] = node_min[3 * src + a]; hi[a][k] = node_max[3 * src + a]; }
             if (sl[k] < 0) continue;
@@ -544,20 +547,27 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
         }
         float4* rec = &s->wnodes[(size_t)ptd::kWideNodeStrideF4 * w];
 #if PT_WIDE_HALF
-        for (int a = 0; a < 3; a++) {  // row a: {lo of slots 0..3, hi of slots 0..3} as fp16, each rounded outwards
-            unsigned short h[8];
-            for (int k = 0; k < 4; k++) {
+        for (int a = 0; a < 3; a++) {  // row a: {lo of slots 0..K-1, hi of slots 0..K-1} as fp16, each rounded outwards
+            unsigned short h[2 * K];
+            for (int k = 0; k < K; k++) {
                 h[k] = half_towards(lo[a][k], false);
-                h[4 + k] = half_towards(hi[a][k], true);
+                h[K + k] = half_towards(hi[a][k], true);
                 // the slot test must never be tighter than the box: checked, not assumed (and no infinities)
-                if (!(half_value(h[k]) <= lo[a][k]) || !(half_value(h[4 + k]) >= hi[a][k]) || (h[k] & 0x7fffu) >= 0x7c00u ||
-                    (h[4 + k] & 0x7fffu) >= 0x7c00u)
+                if (!(half_value(h[k]) <= lo[a][k]) || !(half_value(h[K + k]) >= hi[a][k]) || (h[k] & 0x7fffu) >= 0x7c00u ||
+                    (h[K + k] & 0x7fffu) >= 0x7c00u)
                     return false;  // a plane beyond the fp16 range: this scene takes the literal walk
             }
-            memcpy(&rec[a], h, 16);
+            memcpy((char*)rec + 4 * K * a, h, 4 * K);
         }
-        rec[3] = make_float4(__builtin_bit_cast(float, childBase), __builtin_bit_cast(float, leafBase),
-                             __builtin_bit_cast(float, interiorMask | (leafMask << 4)), 0.0f);
+        if (K == 8) {  // interior slots first: counts instead of masks
+            const int nInt = __builtin_popcount((unsigned)interiorMask), nLf = __builtin_popcount((unsigned)leafMask);
+            if (interiorMask != (1 << nInt) - 1 || leafMask != (((1 << nLf) - 1) << nInt) || nLeaves >= (1 << 24)) return false;
+            rec[6] = make_float4(__builtin_bit_cast(float, childBase), __builtin_bit_cast(float, leafBase),
+                                 __builtin_bit_cast(float, nInt | (nLf << 8)), 0.0f);
+        } else {
+            rec[3] = make_float4(__builtin_bit_cast(float, childBase), __builtin_bit_cast(float, leafBase),
+                                 __builtin_bit_cast(float, interiorMask | (leafMask << 4)), 0.0f);
+        }
 #else
         for (int a = 0; a < 3; a++) {
             rec[2 * a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
@@ -575,11 +585,11 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
         for (int w = 0; w < nw; w++) {
             visits += boxArea(wide[(size_t)w].bnode);
             if (wide[(size_t)w].depth > maxDepth) maxDepth = wide[(size_t)w].depth;
-            for (int k = 0; k < 4; k++)
-                if (slotsOf[(size_t)4 * w + k] >= 0 && isLeaf(slotsOf[(size_t)4 * w + k])) leafOpens += boxArea(slotsOf[(size_t)4 * w + k]);
+            for (int k = 0; k < K; k++)
+                if (slotsOf[(size_t)K * w + k] >= 0 && isLeaf(slotsOf[(size_t)K * w + k])) leafOpens += boxArea(slotsOf[(size_t)K * w + k]);
         }
-        fprintf(stderr, "wide tree (%s): %d nodes, %d leaves, depth %d, expected visits %.3f, expected leaf opens %.3f\n",
-                top == 2 ? "optimised top" : top == 1 ? "rebuilt top" : "reference top", nw, nLeaves, maxDepth, visits / boxArea(0), leafOpens / boxArea(0));
+        fprintf(stderr, "%d-wide tree (%s): %d nodes, %d leaves, depth %d, expected visits %.3f, expected leaf opens %.3f\n",
+                K, top == 2 ? "optimised top" : top == 1 ? "rebuilt top" : "reference top", nw, nLeaves, maxDepth, visits / boxArea(0), leafOpens / boxArea(0));
     }
     return true;
 }
@@ -963,14 +973,22 @@ int mipt_scene_selfcheck_wide(const mipt_scene* s, int* leaves_out, int* depth_o
     const int nw = s->nWide, nLeaves = (int)(s->leafBox.size() / 2);
     std::vector<char> nodeSeen((size_t)nw, 0), leafSeen((size_t)nLeaves, 0);
     struct Box { float lo[3], hi[3]; };
+    constexpr int K = ptd::kWideK;
     auto slotBox = [&](int w, int k) {
         Box b;
         for (int a = 0; a < 3; a++) {
-            unsigned short h[8];
-            memcpy(h, &s->wnodes[(size_t)ptd::kWideNodeStrideF4 * w + a], 16);
-            b.lo[a] = half_value(h[k]); b.hi[a] = half_value(h[4 + k]);
+            unsigned short h[2 * K];
+            memcpy(h, (const char*)&s->wnodes[(size_t)ptd::kWideNodeStrideF4 * w] + 4 * K * a, 4 * K);
+            b.lo[a] = half_value(h[k]); b.hi[a] = half_value(h[K + k]);
         }
         return b;
+    };
+    auto masksOf = [&](int w, int& childBase, int& leafBase, int& imask, int& lmask) {
+        const float4 meta = s->wnodes[(size_t)ptd::kWideNodeStrideF4 * w + (K == 8 ? 6 : 3)];
+        childBase = __builtin_bit_cast(int, meta.x); leafBase = __builtin_bit_cast(int, meta.y);
+        const int m = __builtin_bit_cast(int, meta.z);
+        if (K == 8) { const int ni = m & 255, nl = m >> 8; imask = (1 << ni) - 1; lmask = ((1 << nl) - 1) << ni; }
+        else { imask = m & 15; lmask = (m >> 4) & 15; }
     };
     auto inside = [](const Box& in, const Box& out) {
         for (int a = 0; a < 3; a++)
@@ -986,20 +1004,19 @@ int mipt_scene_selfcheck_wide(const mipt_scene* s, int* leaves_out, int* depth_o
         if (it.w < 0 || it.w >= nw || nodeSeen[(size_t)it.w]) return fail(MIPT_ERR_INVALID, "wide tree: a node is out of range or reached twice");
         nodeSeen[(size_t)it.w] = 1;
         if (it.depth > maxDepth) maxDepth = it.depth;
-        const float4 meta = s->wnodes[(size_t)ptd::kWideNodeStrideF4 * it.w + 3];
-        const int childBase = __builtin_bit_cast(int, meta.x), leafBase = __builtin_bit_cast(int, meta.y), masks = __builtin_bit_cast(int, meta.z);
-        const int imask = masks & 15, lmask = (masks >> 4) & 15;
-        if ((imask & lmask) != 0 || (imask | lmask) == 0) return fail(MIPT_ERR_INVALID, "wide tree: bad slot masks");
+        int childBase, leafBase, imask, lmask;
+        masksOf(it.w, childBase, leafBase, imask, lmask);
+        if ((imask & lmask) != 0 || (imask | lmask) == 0 || ((imask | lmask) >> K) != 0) return fail(MIPT_ERR_INVALID, "wide tree: bad slot masks");
         int ni = 0, nl = 0;
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < K; k++) {
             const Box sb = slotBox(it.w, k);
             if (imask & (1 << k)) {
                 const int c = childBase + ni++;
                 if (c <= it.w || c >= nw) return fail(MIPT_ERR_INVALID, "wide tree: a child id does not point forward");
-                const float4 cm = s->wnodes[(size_t)ptd::kWideNodeStrideF4 * c + 3];
-                const int cmask = __builtin_bit_cast(int, cm.z);
-                for (int j = 0; j < 4; j++)
-                    if (((cmask | (cmask >> 4)) & 15) & (1 << j))
+                int cb, clb, cim, clm;
+                masksOf(c, cb, clb, cim, clm);
+                for (int j = 0; j < K; j++)
+                    if ((cim | clm) & (1 << j))
                         if (!inside(slotBox(c, j), sb)) return fail(MIPT_ERR_INVALID, "wide tree: a slot's box does not contain a box of the node below it");
                 stack.push_back({c, it.depth + 1});
             } else if (lmask & (1 << k)) {

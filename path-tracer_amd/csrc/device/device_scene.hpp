@@ -89,7 +89,19 @@ constexpr int kTriAttrF4 = 8;       // float4 per triAttr record
 #ifndef PT_WIDE_HALF
 #define PT_WIDE_HALF 1  // wide nodes with fp16 planes rounded outwards (64 B, four 16-B rows); 0: fp32 planes (112 B, seven rows)
 #endif
-#if PT_WIDE_HALF
+#ifndef PT_WIDE_K
+#define PT_WIDE_K 8  // slots per wide node: 8 (default since r2: 12 instead of 19 dependent visits per closest-hit ray) or 4; 8 needs PT_WIDE_HALF
+#endif
+constexpr int kWideK = PT_WIDE_K;
+#if PT_WIDE_K == 8
+// EIGHT slots per node: per axis 32 B = {lo of slots 0..7 | hi of slots 0..7} as fp16 rounded outwards, at byte 0 / 32 /
+// 64; meta {bits(childBase), bits(leafBase), bits(nInterior | nLeaf << 8), 0} at byte 96.  The INTERIOR slots come
+// first (slots 0 .. nInterior-1, then the leaves), so slot k's child is childBase + k and its leaf leafBase + k -
+// nInterior, without masks and popcounts.  A ray reads its near planes at (row + 16 [d < 0]) and its far planes at (row
+// + 16 [d >= 0]): two 16-B loads per axis, no selects.  112 B in LDS, 128-B records in the arena (one cache line).
+constexpr int kWideNodeF4 = 7;
+constexpr int kWideNodeStrideF4 = 8;
+#elif PT_WIDE_HALF
 constexpr int kWideNodeF4 = 4;        // 16-B rows per wide node: x, y, z planes as 8 halves {lo of slots 0..3, hi of slots 0..3}, meta
 constexpr int kWideNodeStrideF4 = 4;  // 64-B records, 64-B aligned: a node never straddles a cache line
 #else

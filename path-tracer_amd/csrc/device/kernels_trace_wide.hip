@@ -37,7 +37,11 @@ namespace ptd {
 #define PT_TUNE_WIDE_WAVES 4
 #endif
 #ifndef PT_TUNE_WIDE_BURST
+#if PT_WIDE_K == 8
+#define PT_TUNE_WIDE_BURST 8          // eight-slot nodes: 8: 4.22 ms per closest-hit bench launch, 12: 4.26, 16: 4.40
+#else
 #define PT_TUNE_WIDE_BURST 16         // visits between two votes, closest hit (r2, fp16 nodes: 6: 5.42 ms per bench launch, 8: 5.25, 12: 5.07, 16: 5.09, 24: 5.35; with the rebuilt hierarchy: 8: 4.72, 12: 4.56, 16: 4.53, 20: 4.64)
+#endif
 #endif
 #ifndef PT_TUNE_WIDE_STATIC_SHIFT
 #define PT_TUNE_WIDE_STATIC_SHIFT 2   // the static first chunks cover 1 - 2^-shift of the queue
@@ -71,7 +75,11 @@ namespace ptd {
 #define PT_TUNE_WIDE_REFILL_ANYHIT PT_TUNE_WIDE_REFILL
 #endif
 #ifndef PT_TUNE_WIDE_BURST_ANYHIT
+#if PT_WIDE_K == 8
+#define PT_TUNE_WIDE_BURST_ANYHIT 6   // eight-slot nodes: 2: 1.45 ms per any-hit bench launch, 3: 1.37, 4: 1.39, 6: 1.31, 8: 1.35
+#else
 #define PT_TUNE_WIDE_BURST_ANYHIT 4   // ... any hit: rays end early, shorter bursts waste fewer visits (3: 1.70 ms, 4: 1.62, 6: 1.67)
+#endif
 #endif
 #ifndef PT_TUNE_WIDE_LEAF_ANYHIT
 #define PT_TUNE_WIDE_LEAF_ANYHIT 32    // any-hit rays hold fewer leaves: start their leaf phase earlier (r2: 40/8/16 1.50 ms per bench launch, 32/16/8 1.41)
@@ -87,6 +95,22 @@ namespace ptd {
 // Measured with the rebuilt hierarchy: 1.375 -> 1.28 ms per any-hit bench launch.  The closest-hit instantiation
 // needs 101 VGPRs (5 wavefronts allow 96: three spilled registers) and gains 1.3 % at equal LDS but loses 2.7 % against
 // its big-LDS configuration, so it stays at one 1024-thread block per CU, 4 wavefronts per SIMD.
+#if PT_WIDE_K == 8
+// ... with eight-slot nodes (112 B, 121 VGPRs in the closest-hit and ~100 in the any-hit instantiation) five wavefronts
+// spill 23 registers: both instantiations run one 1024-thread block per CU (any-hit 1.38 ms against 1.82 at five).
+#ifndef PT_TUNE_WIDE_BLOCK_ANYHIT
+#define PT_TUNE_WIDE_BLOCK_ANYHIT 1024
+#endif
+#ifndef PT_TUNE_WIDE_WAVES_ANYHIT
+#define PT_TUNE_WIDE_WAVES_ANYHIT 4
+#endif
+#ifndef PT_TUNE_WIDE_PER_CU_ANYHIT
+#define PT_TUNE_WIDE_PER_CU_ANYHIT 1
+#endif
+#ifndef PT_TUNE_WIDE_TOP_ANYHIT
+#define PT_TUNE_WIDE_TOP_ANYHIT kWideTopNodes
+#endif
+#else
 #ifndef PT_TUNE_WIDE_BLOCK_ANYHIT
 #define PT_TUNE_WIDE_BLOCK_ANYHIT 256
 #endif
@@ -97,7 +121,8 @@ namespace ptd {
 #define PT_TUNE_WIDE_PER_CU_ANYHIT 5
 #endif
 #ifndef PT_TUNE_WIDE_TOP_ANYHIT
-#define PT_TUNE_WIDE_TOP_ANYHIT 216
+#define PT_TUNE_WIDE_TOP_ANYHIT (13824 / (16 * kWideNodeF4))  // 13.5 KB of nodes beside 16 KB of stacks: 216 64-B nodes
+#endif
 #endif
 template <bool ANYHIT> struct WideCfg {
     static constexpr int kBlock = ANYHIT ? PT_TUNE_WIDE_BLOCK_ANYHIT : PT_TUNE_WIDE_BLOCK;
@@ -221,6 +246,21 @@ __device__ __forceinline__ int group_take(unsigned& e) {  // removes the lowest 
     return (int)(e >> 8) + __popc((e >> 4) & 15u & (bit - 1u));
 }
 
+#if PT_WIDE_K == 8
+// eight-slot nodes keep interior slots first: an entry is base << 8 | pending, slot k's item is base + k (for leaf groups
+// the pending bits are already shifted down by the number of interior slots)
+__device__ __forceinline__ int group_take8(unsigned& e) {  // removes the lowest pending slot, returns its item
+    const int k = __builtin_ctz(e);  // the pending bits are the lowest of the entry and not all zero
+    e &= e - 1u;
+    return (int)(e >> 8) + k;
+}
+constexpr unsigned kPendMask = 255u;
+#define PT_GROUP_TAKE group_take8
+#else
+constexpr unsigned kPendMask = 15u;
+#define PT_GROUP_TAKE group_take
+#endif
+
 #ifndef PT_DIAG_UTIL
 #define PT_DIAG_UTIL 0  // diagnostic builds only: 1 / 2 turn the counters into lanes-active / lanes-issued of the visit / leaf phase
 #endif
@@ -269,6 +309,9 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
     unsigned raySlot = 0, queueSlot = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
     int sx = 0, sy = 0, sz = 0;  // 1 where the direction component is negative
+#if PT_WIDE_K == 8
+    unsigned oNx = 0, oFx = 16, oNy = 32, oFy = 48, oNz = 64, oFz = 80;  // byte offsets of this ray's near / far half-rows in a node
+#endif
 #if PT_TUNE_WIDE_FMA
     float ynx = 0, yny = 0, ynz = 0, yfx = 0, yfy = 0, yfz = 0;  // y shrunk / grown, see wide_hit_mask
     float cnx = 0, cny = 0, cnz = 0, cfx = 0, cfy = 0, cfz = 0;  // o y' widened outwards, see wide_hit_mask_fma
@@ -400,6 +443,10 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                         yfx = (float2v)(yx * 0x1.00002p0f); yfy = (float2v)(yy * 0x1.00002p0f); yfz = (float2v)(yz * 0x1.00002p0f);
 #endif
                         sx = dx < 0.0f ? 1 : 0; sy = dy < 0.0f ? 1 : 0; sz = dz < 0.0f ? 1 : 0;
+#if PT_WIDE_K == 8
+                        oNx = (unsigned)sx << 4; oFx = 16u - oNx; oNy = 32u + ((unsigned)sy << 4); oFy = 80u - oNy;
+                        oNz = 64u + ((unsigned)sz << 4); oFz = 144u - oNz;
+#endif
                         bestTri = -1; bestSeq = 0x7fffffff; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
                         w = 0;
                         hasRay = true;
@@ -432,6 +479,64 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
             if (COUNT) { const unsigned long long ma = __ballot(w >= 0 && groups < kWideGroups); if (ma) { nv += (w >= 0 && groups < kWideGroups) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; } }
 #endif
             if (w >= 0 && groups < kWideGroups) {
+#if PT_WIDE_K == 8
+                // seven 16-B pieces per node from either home: near and far half-rows of x, y, z (picked by address), meta
+                half8v nx8, fx8, ny8, fy8, nz8, fz8;
+                float4v meta;
+#define PT_PIECE(AS, T, BASE, OFS) (*(const __attribute__((address_space(AS))) T*)((const __attribute__((address_space(AS))) char*)(BASE) + (OFS)))
+                if (w < nTop) {  // top of the tree: from LDS, 112-B records
+                    const unsigned a = __umul24((unsigned)w, 112u);
+                    nx8 = PT_PIECE(3, half8v, topLds, a + oNx); fx8 = PT_PIECE(3, half8v, topLds, a + oFx);
+                    ny8 = PT_PIECE(3, half8v, topLds, a + oNy); fy8 = PT_PIECE(3, half8v, topLds, a + oFy);
+                    nz8 = PT_PIECE(3, half8v, topLds, a + oNz); fz8 = PT_PIECE(3, half8v, topLds, a + oFz);
+                    meta = PT_PIECE(3, float4v, topLds, a + 96u);
+                } else {  // 128-B records
+                    const unsigned a = (unsigned)w << 7;
+                    nx8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)(a + oNx)); fx8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)(a + oFx));
+                    ny8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)(a + oNy)); fy8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)(a + oFy));
+                    nz8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)(a + oNz)); fz8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)(a + oFz));
+                    meta = PT_PIECE(1, float4v, nodesGlobal, (size_t)(a + 96u));
+                }
+#undef PT_PIECE
+                const int counts = f2i(meta.z);
+                const int nInt = counts & 255, nLeafSlots = counts >> 8;
+                const int imask = (1 << nInt) - 1, lmask = ((1 << nLeafSlots) - 1) << nInt;
+#if !PT_DIAG_UTIL
+                if (COUNT) nv += (unsigned)(nInt + nLeafSlots);
+#endif
+                int hm;
+                if (precise)
+                    hm = wide_hit_mask_sub(widen(nx8.lo), widen(fx8.lo), widen(ny8.lo), widen(fy8.lo), widen(nz8.lo), widen(fz8.lo),
+                                           ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz) |
+                         (wide_hit_mask_sub(widen(nx8.hi), widen(fx8.hi), widen(ny8.hi), widen(fy8.hi), widen(nz8.hi), widen(fz8.hi),
+                                            ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz) << 4);
+                else
+                    hm = wide_hit_mask_fma_h(nx8.lo, fx8.lo, ny8.lo, fy8.lo, nz8.lo, fz8.lo, ynx, yny, ynz, yfx, yfy, yfz, cnx, cny, cnz,
+                                             cfx, cfy, cfz) |
+                         (wide_hit_mask_fma_h(nx8.hi, fx8.hi, ny8.hi, fy8.hi, nz8.hi, fz8.hi, ynx, yny, ynz, yfx, yfy, yfz, cnx, cny,
+                                              cnz, cfx, cfy, cfz) << 4);
+                const int lh = hm & lmask, ih = hm & imask;
+                if (lh != 0) {  // park the candidate leaves of this node as one group
+#pragma unroll
+                    for (int k = kWideGroups - 1; k > 0; k--) g[k] = g[k - 1];
+                    g[0] = ((unsigned)f2i(meta.y) << 8) | (unsigned)(lh >> nInt);
+                    ++groups;
+                }
+                if (ih != 0) {  // the hit children go on top of the stack as one entry
+                    if (tos != 0u) { stack[sp] = tos; sp += kBlk; }
+                    tos = ((unsigned)f2i(meta.x) << 8) | (unsigned)ih;
+                }
+                w = -1;
+                if (tos != 0u) {  // next: the lowest pending child of the top entry
+                    w = group_take8(tos);
+                    if ((tos & 255u) == 0u) {
+                        tos = 0u;
+                        if (sp > 0) { sp -= kBlk; tos = stack[sp]; }
+                    }
+                }
+            }
+        }
+#else
 #if PT_WIDE_HALF
                 // four 16-B rows per node from either home: x, y, z planes as halves {lo0..3, hi0..3}, meta
                 half8v rx, ry, rz;
@@ -516,6 +621,7 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                 }
             }
         }
+#endif  // PT_WIDE_K
         if (hasRay && w < 0 && groups == 0 && cur < 0 && uLeaf < 0) PT_FINISH();  // walked everything, nothing parked, nothing unverified
         // ---- leaves: open parked leaves with the exact box test, test their triangles ----
         const unsigned long long mCanVisit = __ballot(w >= 0 && groups < kWideGroups);
@@ -545,9 +651,9 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                     // one uniform base, 32-bit offsets
                     unsigned triOfs;
                     if (opening) {
-                        curLeaf = group_take(g[0]);
+                        curLeaf = PT_GROUP_TAKE(g[0]);
                         triOfs = headOfs + (unsigned)curLeaf * (16u * kLeafHeadStrideF4);
-                        if ((g[0] & 15u) == 0u) {
+                        if ((g[0] & kPendMask) == 0u) {
 #pragma unroll
                             for (int k = 0; k + 1 < kWideGroups; k++) g[k] = g[k + 1];
                             --groups;
