@@ -10,7 +10,9 @@
 //             (threaded links of StacklessBVH, reference cs488.h:1637-1659; 0 = done)
 //             Device numbering: the root is 0, the kTopNodes nodes with the largest boxes (a connected
 //             top of the tree) come first, the rest follow in preorder; the links are renumbered to match.
-//   wnodes    (PT_WIDE_HALF, the default) 4 x 16 B per 4-wide node: rows x, y, z = 8 halves {lo of slots 0..3, hi of slots
+//   wnodes    (PT_WIDE_K = 8, the default: eight slots per node, 112 B in 128-B records, see kWideNodeF4 below; what
+//             follows describes the four-slot layouts PT_WIDE_K = 4 keeps)
+//             (PT_WIDE_HALF) 4 x 16 B per 4-wide node: rows x, y, z = 8 halves {lo of slots 0..3, hi of slots
 //             0..3}, fp16 rounded OUTWARDS (lo down, hi up: the slot test only has to be conservative), row 3 =
 //             {bits(childBase), bits(leafBase), bits(interiorMask | leafMask << 4), 0}; 64 B, never straddling a line.
 //             Scenes with a plane beyond the fp16 range take the literal walk.  With PT_WIDE_HALF=0:

@@ -1,4 +1,5 @@
-// kernels_trace_wide.hip -- the order-free traversal over the 4-wide tree.
+// kernels_trace_wide.hip -- the order-free traversal over the wide tree (eight slots per node by default, PT_WIDE_K;
+// the text below was written for four and holds for any width).
 //
 // Why the reference's results do not depend on HOW the leaves are found.  The reference walks its binary tree in a
 // fixed order and tests a leaf's triangles iff the leaf's box AND the boxes of all its ancestors pass
