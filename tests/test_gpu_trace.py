@@ -411,3 +411,37 @@ def test_every_hierarchy_over_the_references_leaves_gives_the_oracles_hits(B, ob
         assert np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(bits(got[2]), bits(ref[2])), (top, collapse)
         assert np.array_equal(ctx.occluded(o, d, 1e-4, 0.6 * float(np.linalg.norm(hi - lo))), ref_occ), (top, collapse, "any hit")
     assert visits[("optimised", "optimal")] < visits[("reference", "greedy")]
+
+
+@pytest.mark.parametrize("scale,expect_wide", [(3.0e5, False), (3.0e-5, True), (700.0, True)])
+def test_scenes_at_the_edges_of_the_fp16_node_planes(B, ob, sf, scale, expect_wide):
+    """The wide nodes store their planes as fp16 rounded outwards.  A scene scaled by 3e5 has planes beyond fp16's 65504:
+    build_wide must refuse it (wide_nodes == 0) and every ray takes the literal walk.  A scene scaled by 3e-5 has planes
+    in fp16's subnormal range (spacing 6e-8; smaller scenes fall under the reference's own t > 0.00001, cs488.h:812),
+    and one scaled by 700 sits where fp16's spacing is 32 units: the slot test gets very loose, the answer must not
+    change -- admission rests on the exact fp32 leaf box.  Hits, barycentrics and the any-hit answer against the oracle,
+    bit for bit, on primary and incoherent rays."""
+    base = sf.load_scene_arrays("cornellbox")
+    arrays = [np.array(a) if isinstance(a, np.ndarray) else a for a in base]
+    k = np.float32(scale)
+    arrays[0] = (np.asarray(arrays[0], np.float32) * k).astype(np.float32)
+    scene = sf.product_scene_from_mesh_arrays(*arrays)
+    assert scene.exact_reciprocal
+    assert (scene.wide_nodes > 0) == expect_wide
+    scene.selfcheck_wide()
+    ctx = B.Context(scene, device=0)
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+    o, d = ctx.eye_rays(B.default_camera(128, 96))
+    o = (o * k).astype(np.float32)
+    rng = np.random.default_rng(5)
+    pos = np.asarray(arrays[0], np.float32).reshape(-1, 3)
+    lo, hi = pos.min(0), pos.max(0)
+    o2 = (lo + (hi - lo) * rng.uniform(0.02, 0.98, (20000, 3))).astype(np.float32)
+    d2 = rng.normal(size=(20000, 3)).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True).astype(np.float32)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    a, b = ctx.trace(o, d), orc.intersect(o, d)
+    assert (b[0] >= 0).sum() > 5000
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[2]), bits(b[2]))
+    tmax = float(0.5 * np.linalg.norm(hi - lo))
+    assert np.array_equal(ctx.occluded(o, d, 0.0, tmax), orc.occluded(o, d, 0.0, tmax))
