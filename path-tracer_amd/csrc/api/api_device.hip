@@ -253,7 +253,7 @@ static void rebuild_top(const mipt_scene_desc* d, BinTree& t) {
 // nodes are renumbered parents first (the collapse sweeps rely on children having larger ids).
 static void optimise_top(BinTree& t) {
     const int n = t.size();
-    if (n < 7) return;
+    if (n < 7 || n > 2000000) return;  // nothing to move / more than a million leaves: the passes would take minutes, the SAH build alone has to do
     std::vector<int> parent((size_t)n, -1);
     for (int i = 0; i < n; i++)
         if (t.refLeaf[(size_t)i] < 0) { parent[(size_t)t.left[(size_t)i]] = i; parent[(size_t)t.right[(size_t)i]] = i; }
