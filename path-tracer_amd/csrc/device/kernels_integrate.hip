@@ -150,6 +150,12 @@ __device__ __forceinline__ vec3 pending_light(const PathBuffers& pb, unsigned p,
     return L;
 }
 
+#ifndef PT_TUNE_SHADE_WAVES
+#define PT_TUNE_SHADE_WAVES 6  // 80 VGPRs, no spills (0 = the compiler's choice: 97 VGPRs, 5 wavefronts per SIMD, 3 % slower; 7: spills, 6 % slower)
+#endif
+#if PT_TUNE_SHADE_WAVES
+__attribute__((amdgpu_waves_per_eu(PT_TUNE_SHADE_WAVES, PT_TUNE_SHADE_WAVES)))
+#endif
 __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams fp, PathBuffers pb, int it, int finalsOnly) {
     const int nl = pb.nLights;
     const bool fold = nl == 1;  // see FLAG_FOLDED
