@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_rgb8(const float* __restrict__ 
 
 // ---- launchers ----
 #ifndef PT_TUNE_INTEGRATE_GRID
-#define PT_TUNE_INTEGRATE_GRID 32768  // 8192: 10.30 ms of shading per bench step, 16384: 10.23, 32768: 10.13, one item per thread: 10.42
+#define PT_TUNE_INTEGRATE_GRID 65536  // r1, 5 wavefronts: 8192: 10.30 ms of shading per bench step, 16384: 10.23, 32768: 10.13, one item per thread: 10.42; r2, 6 wavefronts: 32768: 9.79, 65536: 9.6, 131072: 9.7
 #endif
 constexpr size_t kIntegrateGrid = PT_TUNE_INTEGRATE_GRID;  // blocks of the grid-strided integrator kernels
 static inline unsigned grid_for(size_t n) {
