@@ -265,6 +265,24 @@ def test_headless_cli_renders_and_reuses_its_cache(B, tmp_path):
     assert np.array_equal(read_pfm(pfm).view(np.uint32), want.view(np.uint32))
 
 
+def test_headless_cli_over_the_gpus_of_a_node(B, tmp_path):
+    """mipt_render --gpus N renders through mipt_node_* (a context, stream and thread per GPU, one RCCL gather): with the
+    one GPU a test box has, the frame must equal the plain CLI run bit for bit, in path and in direct mode; asking for
+    more GPUs than there are is an error message and a non-zero exit, not a hang"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(B.LIB_PATH), "mipt_render")
+    for mode_args in (["--mode", "path", "--spp", "3", "--bounces", "4", "--seed", "2"], ["--mode", "direct"]):
+        plain, node = str(tmp_path / "plain.pfm"), str(tmp_path / "node.pfm")
+        base = [exe, "--width", "200", "--height", "150"] + mode_args
+        a = subprocess.run(base + ["--out-pfm", plain], capture_output=True, text=True, timeout=120)
+        b = subprocess.run(base + ["--gpus", "1", "--out-pfm", node], capture_output=True, text=True, timeout=120)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        assert np.array_equal(read_pfm(plain).view(np.uint32), read_pfm(node).view(np.uint32)), mode_args
+    bad = subprocess.run([exe, "--width", "64", "--height", "64", "--gpus", "64", "--out-pfm", str(tmp_path / "x.pfm")],
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and bad.stderr.strip()
+
+
 def test_overlapped_and_serialised_bounces_give_the_same_frame(B, ob, sf):
     """mipt_context_set_overlap: the shadow rays of bounce k on a side stream beside the extension rays of bounce k+1
     (default) against everything on one stream -- same bits, deep paths included (Russian roulette from bounce 6 on)"""
