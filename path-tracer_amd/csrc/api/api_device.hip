@@ -81,6 +81,7 @@ struct mipt_scene {
     bool hasSpecular = false;   // some material is metal or glass: only then does shade() recurse (C:2455-2490)
     bool btOk = false;
     int nWide = 0;
+    float wideInvScale = 1.0f;  // 1 / S: the wide nodes' fp16 planes are the scene's planes times S, a power of two
     bool wideOk = false;
 };
 
@@ -565,6 +566,24 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
     const int nw = (int)wide.size();
     slotsOf.resize((size_t)K * nw, -1);
     s->wnodes.assign((size_t)ptd::kWideNodeStrideF4 * nw, make_float4(0, 0, 0, 0));
+    // fp16 holds magnitudes up to 65504 and is coarse below 6e-5: the planes are stored times a power of two S that
+    // brings the largest magnitude of the tree into [16384, 32768) -- exact in fp32, undone exactly in the kernel (it
+    // multiplies the ray's reciprocals by 1 / S), so every tame scene keeps fp16's full relative precision
+    float planeScale = 1.0f;
+    {
+        float big = 0.0f;
+        for (int i = 0; i < n; i++)
+            for (int a = 0; a < 3; a++) big = std::max(big, std::max(std::fabs(node_min[3 * i + a]), std::fabs(node_max[3 * i + a])));
+        if (big > 0.0f && std::isfinite(big)) {
+            int e = 0;
+            (void)std::frexp(big, &e);  // big = m 2^e, m in [0.5, 1)
+            planeScale = std::ldexp(1.0f, 15 - e);
+        }
+    }
+#if !PT_WIDE_HALF
+    planeScale = 1.0f;  // fp32 planes are stored as they are
+#endif
+    s->wideInvScale = 1.0f / planeScale;
     // second pass: records (children of wide node w start at its childBase, in the order the first pass appended them)
     int nextChild = 1;
     for (int w = 0; w < nw; w++) {
@@ -573,7 +592,7 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
         float lo[3][K], hi[3][K];
         for (int k = 0; k < K; k++) {
             const int src = sl[k] >= 0 ? sl[k] : sl[0];  // an empty slot repeats slot 0's (tame) box; the masks leave it out
-            for (int a = 0; a < 3; a++) { lo[a][k] = node_min[3 * src + a]; hi[a][k] = node_max[3 * src + a]; }
+            for (int a = 0; a < 3; a++) { lo[a][k] = node_min[3 * src + a] * planeScale; hi[a][k] = node_max[3 * src + a] * planeScale; }
             if (sl[k] < 0) continue;
             if (isLeaf(sl[k])) {
                 leafMask |= 1 << k;
@@ -1024,7 +1043,7 @@ int mipt_scene_selfcheck_wide(const mipt_scene* s, int* leaves_out, int* depth_o
         for (int a = 0; a < 3; a++) {
             unsigned short h[2 * K];
             memcpy(h, (const char*)&s->wnodes[(size_t)ptd::kWideNodeStrideF4 * w] + 4 * K * a, 4 * K);
-            b.lo[a] = half_value(h[k]); b.hi[a] = half_value(h[K + k]);
+            b.lo[a] = half_value(h[k]) * s->wideInvScale; b.hi[a] = half_value(h[K + k]) * s->wideInvScale;
         }
         return b;
     };
@@ -1172,6 +1191,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     // k_trace_wide addresses leafHead and leafTris with 32-bit offsets from leafTris
     c->ds.nWide = (s->wideOk && oLeafHead + szLeafHead - oLeaf < ((size_t)1 << 32)) ? s->nWide : 0;
     c->ds.nWideTop = s->nWide < ptd::kWideTopNodes ? s->nWide : ptd::kWideTopNodes;
+    c->ds.wideInvScale = s->wideInvScale;
     if (hipMalloc((void**)&c->dTotals, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->dTotals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         return fail(MIPT_ERR_DEVICE, "hipMalloc(stats) failed");

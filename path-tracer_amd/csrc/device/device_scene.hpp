@@ -68,6 +68,8 @@ struct DevScene {
     const int4* btLinks;    // {idRight, idParent, idSibling, 0} per node (device numbering): StacklessBVH2's links, only when btOk
     int btOk;               // the tree is a verified binary tree of depth <= 31: k_trace_bittrail may run
     int nWide, nWideTop;    // wide nodes [0, nWideTop) are kept in LDS by k_trace_wide
+    float wideInvScale;     // the fp16 planes of the wide nodes are the scene's planes times a power of two S (so that any
+                            // tame scene fits fp16's range at full relative precision); this is 1 / S
     int nTopNodes;   // nodes [0, nTopNodes) are the top of the tree, numbered first so that k_trace can hold them in LDS
     int handBackAll; // test switch (MIPT_HAND_BACK_ALL=1 when the context is made): k_trace_wide hands EVERY ray to the exact walk kernels
     int planesTame;  // every box plane is 0 or has magnitude in [2^-61, 2^40] and min <= max: the exact reciprocal slab division may be used (traverse.hpp)

@@ -224,7 +224,8 @@ __device__ __forceinline__ int wide_hit_mask_fma_h(const half4v nearx, const hal
 #undef PT_F
     return (!(u0 > v0) ? 1 : 0) | (!(u1 > v1) ? 2 : 0) | (!(u2 > v2) ? 4 : 0) | (!(u3 > v3) ? 8 : 0);
 }
-__device__ __forceinline__ float4v widen(const half4v h) { return float4v{(float)h.x, (float)h.y, (float)h.z, (float)h.w}; }
+// fp16 planes back to the scene's scale (k = DevScene::wideInvScale, a power of two: exact)
+__device__ __forceinline__ float4v widen(const half4v h, const float k) { return float4v{(float)h.x * k, (float)h.y * k, (float)h.z * k, (float)h.w * k}; }
 #endif
 // the subtract-and-multiply form on scalar reciprocals (the `precise` lanes of a kernel built with the fma form)
 __device__ __forceinline__ int wide_hit_mask_sub(const float4v nearx, const float4v farx, const float4v neary, const float4v fary,
@@ -439,6 +440,15 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                             cfz = __builtin_fmaf(__builtin_fabsf(bz), -0x1p-22f, bz);
                         }
                         precise = !(mag_within(dx, -12, kDirHi) && mag_within(dy, -12, kDirHi) && mag_within(dz, -12, kDirHi));
+#if PT_WIDE_HALF
+                        // the stored planes are p S with S a power of two (DevScene::wideInvScale = 1 / S): p S (y' / S) is the
+                        // same real product, and y' / S is exact, so the fma form sees no difference; the constants c were
+                        // formed from the unscaled y'.  `precise` lanes keep the unscaled y' and unscale the planes instead.
+                        if (!precise) {
+                            ynx *= s.wideInvScale; yny *= s.wideInvScale; ynz *= s.wideInvScale;
+                            yfx *= s.wideInvScale; yfy *= s.wideInvScale; yfz *= s.wideInvScale;
+                        }
+#endif
 #else
                         ynx = (float2v)(yx * 0x1.ffffcp-1f); yny = (float2v)(yy * 0x1.ffffcp-1f); ynz = (float2v)(yz * 0x1.ffffcp-1f);
                         yfx = (float2v)(yx * 0x1.00002p0f); yfy = (float2v)(yy * 0x1.00002p0f); yfz = (float2v)(yz * 0x1.00002p0f);
@@ -507,9 +517,9 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
 #endif
                 int hm;
                 if (precise)
-                    hm = wide_hit_mask_sub(widen(nx8.lo), widen(fx8.lo), widen(ny8.lo), widen(fy8.lo), widen(nz8.lo), widen(fz8.lo),
+                    hm = wide_hit_mask_sub(widen(nx8.lo, s.wideInvScale), widen(fx8.lo, s.wideInvScale), widen(ny8.lo, s.wideInvScale), widen(fy8.lo, s.wideInvScale), widen(nz8.lo, s.wideInvScale), widen(fz8.lo, s.wideInvScale),
                                            ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz) |
-                         (wide_hit_mask_sub(widen(nx8.hi), widen(fx8.hi), widen(ny8.hi), widen(fy8.hi), widen(nz8.hi), widen(fz8.hi),
+                         (wide_hit_mask_sub(widen(nx8.hi, s.wideInvScale), widen(fx8.hi, s.wideInvScale), widen(ny8.hi, s.wideInvScale), widen(fy8.hi, s.wideInvScale), widen(nz8.hi, s.wideInvScale), widen(fz8.hi, s.wideInvScale),
                                             ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz) << 4);
                 else
                     hm = wide_hit_mask_fma_h(nx8.lo, fx8.lo, ny8.lo, fy8.lo, nz8.lo, fz8.lo, ynx, yny, ynz, yfx, yfy, yfz, cnx, cny, cnz,
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                 const half4v nearx = sx ? rx.hi : rx.lo, farx = sx ? rx.lo : rx.hi;
                 const half4v neary = sy ? ry.hi : ry.lo, fary = sy ? ry.lo : ry.hi;
                 const half4v nearz = sz ? rz.hi : rz.lo, farz = sz ? rz.lo : rz.hi;
-                const int hm = precise ? wide_hit_mask_sub(widen(nearx), widen(farx), widen(neary), widen(fary), widen(nearz), widen(farz),
+                const int hm = precise ? wide_hit_mask_sub(widen(nearx, s.wideInvScale), widen(farx, s.wideInvScale), widen(neary, s.wideInvScale), widen(fary, s.wideInvScale), widen(nearz, s.wideInvScale), widen(farz, s.wideInvScale),
                                                            ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz)
                                        : wide_hit_mask_fma_h(nearx, farx, neary, fary, nearz, farz, ynx, yny, ynz, yfx, yfy, yfz, cnx, cny,
                                                              cnz, cfx, cfy, cfz);

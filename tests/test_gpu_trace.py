@@ -413,14 +413,13 @@ def test_every_hierarchy_over_the_references_leaves_gives_the_oracles_hits(B, ob
     assert visits[("optimised", "optimal")] < visits[("reference", "greedy")]
 
 
-@pytest.mark.parametrize("scale,expect_wide", [(3.0e5, False), (3.0e-5, True), (700.0, True)])
+@pytest.mark.parametrize("scale,expect_wide", [(3.0e5, True), (3.0e-5, True), (700.0, True), (2.0e11, True)])
 def test_scenes_at_the_edges_of_the_fp16_node_planes(B, ob, sf, scale, expect_wide):
-    """The wide nodes store their planes as fp16 rounded outwards.  A scene scaled by 3e5 has planes beyond fp16's 65504:
-    build_wide must refuse it (wide_nodes == 0) and every ray takes the literal walk.  A scene scaled by 3e-5 has planes
-    in fp16's subnormal range (spacing 6e-8; smaller scenes fall under the reference's own t > 0.00001, cs488.h:812),
-    and one scaled by 700 sits where fp16's spacing is 32 units: the slot test gets very loose, the answer must not
-    change -- admission rests on the exact fp32 leaf box.  Hits, barycentrics and the any-hit answer against the oracle,
-    bit for bit, on primary and incoherent rays."""
+    """The wide nodes store their planes as fp16 rounded outwards, times a power of two chosen per scene so that the
+    largest plane lands in [16384, 32768): a scene scaled by 3e5 or 2e11 (planes far beyond fp16's 65504) or by 3e-5
+    (planes in what would be fp16's subnormal range; smaller scenes fall under the reference's own t > 0.00001,
+    cs488.h:812) must qualify for the wide traversal like any other and return the oracle's hits, barycentrics and
+    any-hit answers bit for bit, on primary and incoherent rays -- admission rests on the exact fp32 leaf box."""
     base = sf.load_scene_arrays("cornellbox")
     arrays = [np.array(a) if isinstance(a, np.ndarray) else a for a in base]
     k = np.float32(scale)
