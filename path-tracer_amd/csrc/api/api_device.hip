@@ -80,6 +80,7 @@ struct mipt_scene {
     std::vector<int4> btLinks;  // StacklessBVH2 links in device numbering
     bool hasSpecular = false;   // some material is metal or glass: only then does shade() recurse (C:2455-2490)
     bool btOk = false;
+    bool slowOk = false;  // binary tree of depth <= 96: k_trace_slow may run
     int nWide = 0;
     float wideInvScale = 1.0f;  // 1 / S: the wide nodes' fp16 planes are the scene's planes times S, a power of two
     bool wideOk = false;
@@ -970,6 +971,7 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
                 if (depthOf[l] > maxDepth) maxDepth = depthOf[l];
             }
             s->btOk = maxDepth <= 31;  // the reference's 32-bit trail holds one bit per level
+            s->slowOk = maxDepth <= 96;  // k_trace_slow: depth < kSlowReserve - 128 (since round 2 the wide tree no longer bounds the given tree's depth)
         }
         // textures -> one byte pool
         std::vector<int> texOfs((size_t)d->n_textures, 0);
@@ -1187,6 +1189,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.nodeRight = (const int*)(base + oRight);
     c->ds.btLinks = (const int4*)(base + oBt);
     c->ds.btOk = s->btOk ? 1 : 0;
+    c->ds.slowOk = s->slowOk ? 1 : 0;
     c->hasSpecular = s->hasSpecular;
     // k_trace_wide addresses leafHead and leafTris with 32-bit offsets from leafTris
     c->ds.nWide = (s->wideOk && oLeafHead + szLeafHead - oLeaf < ((size_t)1 << 32)) ? s->nWide : 0;

@@ -67,6 +67,8 @@ struct DevScene {
     const int* nodeRight;   // right child of every interior node (device numbering; 0 for leaves), only when nWide > 0
     const int4* btLinks;    // {idRight, idParent, idSibling, 0} per node (device numbering): StacklessBVH2's links, only when btOk
     int btOk;               // the tree is a verified binary tree of depth <= 31: k_trace_bittrail may run
+    int slowOk;             // ... of depth <= 96: k_trace_slow's node stack holds every state of its walk (deeper trees hand
+                            // their few awkward rays to the literal k_trace, a lane per ray)
     int nWide, nWideTop;    // wide nodes [0, nWideTop) are kept in LDS by k_trace_wide
     float wideInvScale;     // the fp16 planes of the wide nodes are the scene's planes times a power of two S (so that any
                             // tame scene fits fp16's range at full relative precision); this is 1 / S

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
     // remap != nullptr: the queue is the list remap[0 .. *remapCount) of queue slots (the rays k_trace_wide handed
     // back, kernels_trace_wide.hip); most launches find it empty
     // (short lists belong to k_trace_slow below: a wavefront per ray instead of a lane per ray)
-    if (remap && (*remapCount <= kSlowMaxRays || (size_t)blockIdx.x * kTraceBlock >= (size_t)*remapCount)) return;  // a block per kTraceBlock listed rays is plenty
+    if (remap && ((*remapCount <= kSlowMaxRays && s.slowOk) || (size_t)blockIdx.x * kTraceBlock >= (size_t)*remapCount)) return;  // a block per kTraceBlock listed rays is plenty
     __shared__ float4 top[2 * kTopNodes];
     __shared__ unsigned prefix[kShards + 1];
     const int lane = threadIdx.x & 63;
@@ -403,7 +403,7 @@ void launch_divcheck(hipStream_t st, unsigned seed, unsigned blocks, unsigned pe
 // walk's, so ties in t go to the smaller leafTris index, which IS the walk's order (as in k_trace_wide).  Only for
 // trees that build_wide has verified (s.nodeRight exists only then).  The stack cannot overflow: above
 // kSlowStack - kSlowReserve entries a step pops one node, which is a plain depth-first walk and adds at most one
-// entry per level (binary depth <= 3 * kWideMaxDepth < kSlowReserve - 128).
+// entry per level (binary depth <= 96 < kSlowReserve - 128: DevScene::slowOk, checked when the scene is made).
 template <bool ANYHIT, bool COUNT>
 __global__ __launch_bounds__(64) void k_trace_slow(DevScene s, const float4* __restrict__ rays, const int* __restrict__ index,
                                                    const int* __restrict__ target, float4* __restrict__ hits,
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void k_trace_slow(DevScene s, const float4* __r
                                                    const int* __restrict__ list, const unsigned* __restrict__ listCount) {
     __shared__ int stack[kSlowStack];
     const unsigned n = *listCount;
-    if (n > kSlowMaxRays) return;  // k_trace takes long lists
+    if (n > kSlowMaxRays || !s.slowOk) return;  // k_trace takes long lists, and every list of a tree too deep for this stack
     const int lane = threadIdx.x;
     const unsigned long long below = (1ull << lane) - 1ull;
     const __attribute__((address_space(1))) float4v* nodesGlobal = (const __attribute__((address_space(1))) float4v*)s.nodes;

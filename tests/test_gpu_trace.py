@@ -444,3 +444,68 @@ def test_scenes_at_the_edges_of_the_fp16_node_planes(B, ob, sf, scale, expect_wi
     assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[2]), bits(b[2]))
     tmax = float(0.5 * np.linalg.norm(hi - lo))
     assert np.array_equal(ctx.occluded(o, d, 0.0, tmax), orc.occluded(o, d, 0.0, tmax))
+
+
+def test_a_given_tree_three_hundred_levels_deep(B, ob, sf):
+    """Since round 2 the wide traversal walks a hierarchy of the library's own over the GIVEN tree's leaves, so the given
+    tree's depth no longer limits it -- but k_trace_slow, which re-traces the few awkward rays on the given tree with a
+    node stack in LDS, has a limit of its own (96 levels; deeper trees hand those rays to the stackless literal walk).
+    A hand-made chain BVH over 300 separate triangles (every interior node = one leaf + the rest: 299 levels; the
+    reference's builder would never make it, the C-ABI accepts any proper tree): the scene must qualify for the wide
+    traversal, and generic rays, axis-parallel rays (handed back: zero direction components) and a batch long enough
+    for the list-mode kernel must all return the tree-independent brute-force oracle's hits bit for bit."""
+    import ctypes as C
+    n = 300
+    i = np.arange(n, dtype=np.float32)
+    p0 = np.stack([i, 0 * i, 0.05 * (i % 3)], 1); p1 = p0 + np.float32([0.8, 0.0, 0.0]); p2 = p0 + np.float32([0.4, 0.8, 0.02])
+    pos = np.stack([p0, p1, p2], 1).astype(np.float32)                       # (n, 3, 3)
+    nrm = np.tile(np.float32([0, 0, 1]), (n, 3, 1)); uv = np.zeros((n, 3, 2), np.float32); mid = np.zeros(n, np.int32)
+    base = sf.load_scene_arrays("cornellbox")
+    mats, texs = base[4][:1], []
+    arrays = (pos.reshape(-1), nrm.reshape(-1), uv.reshape(-1), mid, mats, texs)
+    mesh = B.Mesh.from_arrays(*arrays)
+    scene_ref = B.Scene(mesh)                                                 # the library's own (reference) build: for the desc
+    lo, hi = pos.min(1), pos.max(1)                                           # per triangle
+    nn = 2 * n - 1
+    node_min, node_max = np.zeros((nn, 3), np.float32), np.zeros((nn, 3), np.float32)
+    id_hit, id_miss = np.zeros(nn, np.int32), np.zeros(nn, np.int32)
+    leaf_first, leaf_count = np.zeros(nn, np.int32), np.zeros(nn, np.int32)
+    suffix_lo = np.minimum.accumulate(lo[::-1], 0)[::-1]; suffix_hi = np.maximum.accumulate(hi[::-1], 0)[::-1]
+    for k in range(n - 1):                                                    # interior 2k: leaf k | everything after it
+        node_min[2 * k], node_max[2 * k] = suffix_lo[k], suffix_hi[k]
+        id_hit[2 * k], id_miss[2 * k] = 2 * k + 1, 0
+        node_min[2 * k + 1], node_max[2 * k + 1] = lo[k], hi[k]
+        id_hit[2 * k + 1] = id_miss[2 * k + 1] = 2 * k + 2
+        leaf_first[2 * k + 1], leaf_count[2 * k + 1] = k, 1
+    node_min[nn - 1], node_max[nn - 1] = lo[n - 1], hi[n - 1]
+    leaf_first[nn - 1], leaf_count[nn - 1] = n - 1, 1
+    tri_index = np.arange(n, dtype=np.int32)
+    d = B.SceneDesc()
+    C.pointer(d)[0] = scene_ref.desc
+    keep = [np.ascontiguousarray(a) for a in (node_min.reshape(-1), node_max.reshape(-1), id_hit, id_miss, leaf_first, leaf_count, tri_index)]
+    d.n_nodes = nn
+    for name, arr in zip(("node_min", "node_max", "id_hit", "id_miss", "leaf_first", "leaf_count", "tri_index"), keep):
+        setattr(d, name, arr.ctypes.data_as(type(getattr(d, name))))
+    d.n_tri_index = n
+    h = C.c_void_p()
+    B.check(B.lib().mipt_scene_create(C.byref(d), C.byref(h)))
+    deep = B.Scene.__new__(B.Scene)
+    deep.h, deep.mesh, deep.bvh, deep.env, deep.lights, deep.desc, deep._keep = h, mesh, scene_ref.bvh, None, scene_ref.lights, d, keep
+    assert deep.wide_nodes > 0
+    leaves, depth = deep.selfcheck_wide()
+    assert leaves == n and depth < 16
+    ctx = B.Context(deep, device=0)
+    orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+    rng = np.random.default_rng(9)
+    m = 20000
+    o = np.stack([rng.uniform(-1, n + 1, m), rng.uniform(-0.5, 1.3, m), np.full(m, 3.0)], 1).astype(np.float32)
+    dgen = rng.normal(size=(m, 3)).astype(np.float32); dgen[:, 2] = -np.abs(dgen[:, 2]) - 0.5
+    dgen /= np.linalg.norm(dgen, axis=1, keepdims=True).astype(np.float32)
+    down = np.tile(np.float32([0, 0, -1]), (m, 1))                            # two zero components: every one handed back
+    for dirs, label in ((dgen, "generic"), (down[:3000], "axis-parallel, short list"), (down, "axis-parallel, long list")):
+        oo = o[: len(dirs)]
+        got = ctx.trace(oo, dirs)
+        ref = orc.intersect(oo, dirs, variant=ob.BRUTEFORCE)
+        assert (ref[0] >= 0).sum() > len(dirs) // 20, label
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(bits(got[2]), bits(ref[2])), label
+        assert np.array_equal(ctx.occluded(oo, dirs, 0.0, 10.0), orc.occluded(oo, dirs, 0.0, 10.0)), label
