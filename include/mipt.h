@@ -255,10 +255,11 @@ void mipt_scene_destroy(mipt_scene*);
  * sequence; 0: every ray of this scene takes the literal IEEE-division slab test.  Results are bit-identical
  * either way; only the speed differs.  No counterpart in the reference. */
 int mipt_scene_exact_reciprocal(const mipt_scene*);
-/* Number of nodes of the 4-wide tree the library built over the scene's leaves for its order-free traversal kernel,
- * or 0 when the scene does not qualify (box planes outside the range above, boxes not nested child-inside-parent,
- * not a binary tree, deeper than 32 levels) and every ray takes the literal threaded walk of
- * StacklessBVH::intersect (C:1661-1683).  Results are bit-identical either way.  No counterpart in the reference. */
+/* Number of nodes of the wide tree (eight slots per node) the library built over the scene's LEAVES for its
+ * order-free traversal kernel, or 0 when the scene does not qualify (box planes outside the range above, boxes not
+ * nested child-inside-parent, not a binary tree) and every ray takes the literal threaded walk of
+ * StacklessBVH::intersect (C:1661-1683).  The depth of the given tree does not matter.  Results are bit-identical
+ * either way.  No counterpart in the reference. */
 int mipt_scene_wide_nodes(const mipt_scene*);
 /* Host-side check (no GPU) of what the order-free traversal rests on: the 4-wide tree -- a hierarchy of the library's
  * own over the reference's LEAVES, see DESIGN.md 4 -- reaches every leaf exactly once, and every slot's stored box
