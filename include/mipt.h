@@ -365,6 +365,16 @@ int mipt_buffer_download(mipt_ctx* ctx, void* host_ptr, const void* dev_ptr, siz
  * `/`; this runs that sequence against `/` on n_pairs operand pairs on the GPU and reports the mismatches (0). */
 int mipt_selftest_fast_division(mipt_ctx* ctx, uint64_t n_pairs, uint32_t seed, uint64_t* mismatches);
 
+/* Self-test (no counterpart in the reference): the library's own vector primitives (csrc/pt/vec.hpp, shared by host and
+ * device code) over arrays of float3, so that tests can compare them bit for bit with the reference's linalg.h
+ * (linalg.h:367, :401, :500-504, :536, :567 -- SURVEY 8(a) row 3; tests/test_ref_pins.py holds vectors produced by the
+ * unmodified header).  ctx == NULL: the host build; otherwise the device build, on that context's GPU.
+ * op: 0 dot(a,b) -> n | 1 cross(a,b) -> 3n | 2 normalize(a) -> 3n | 3 determinant of the matrix with COLUMNS a,b,c -> n |
+ *     4 mul(mat(a,b,c), d) -> 3n | 5 length2(a) -> n | 6 normalize(float2(a.x, a.y)) -> 2n | 7 a / b componentwise -> 3n.
+ * a..d: n float3 each (those the op does not use may be NULL); out: host memory. */
+int mipt_selftest_vec_ops(mipt_ctx* ctx, int op, const float* a, const float* b, const float* c, const float* d, size_t n,
+                          float* out);
+
 /* Which of the reference's traversals answers mipt_trace / mipt_occluded / the render loops of this context.
  * All three return the same bits on every ray tested; they differ in the work they do.
  *   DEFAULT   StacklessBVH::intersect / isHit (C:1661-1705) semantics through the order-free 4-wide traversal

@@ -26,6 +26,12 @@ def build(force=False):
     return LIB_PATH
 
 
+def build_ref():
+    """oracle/_ref: the reference's linalg.h and stb_image.h, unmodified, by include path (oracle/Makefile `ref`); a
+    no-op where /root/reference is absent (the GPU box uses the prebuilt files, or the committed vectors)"""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
 class Camera(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("eye", C.c_float * 3), ("up", C.c_float * 3),
                 ("viewDir", C.c_float * 3), ("aspect", C.c_float), ("filmSize", C.c_float),
@@ -57,6 +63,7 @@ def lib():
                                     C.POINTER(C.c_longlong)]
         L.orc_occluded.argtypes = [vp, C.c_int, C.c_longlong, fp, fp, fp, fp, C.POINTER(C.c_ubyte)]
         L.orc_background.argtypes = [vp, C.c_longlong, fp, fp]
+        L.orc_vec_ops.argtypes = [C.c_int, fp, fp, fp, fp, C.c_longlong, fp]
         L.orc_pcg32_rand.restype = C.c_float
         L.orc_counter_u32.restype = C.c_uint32
         L.orc_counter_u32.argtypes = [C.c_uint32] * 4
@@ -220,3 +227,70 @@ def fnv1a32_of_bits(values_u32):
     for b in values_u32.tolist():
         h = ((h ^ b) * 16777619) & 0xFFFFFFFF
     return h
+
+
+VEC_OUT_WIDTH = (1, 3, 3, 1, 3, 1, 2, 3)  # floats per element: dot cross normalize det3 mul length2 normalize2 div
+
+
+def vec_ops(op, a, b=None, c=None, d=None, fn=None):
+    """orc_vec_ops (the linalg restatement at the top of pt_oracle.c) over (n, 3) float32 arrays; fn: another library's
+    function of the same signature (oracle/_ref/libref_linalg.so: ref_vec_ops)"""
+    arrs = [None if x is None else np.ascontiguousarray(x, np.float32).reshape(-1, 3) for x in (a, b, c, d)]
+    n = arrs[0].shape[0]
+    out = np.empty((n, VEC_OUT_WIDTH[op]), np.float32)
+    fp = C.POINTER(C.c_float)
+    ptrs = [x.ctypes.data_as(fp) if x is not None else None for x in arrs]
+    rc = (fn or lib().orc_vec_ops)(op, *ptrs, n, out.ctypes.data_as(fp))
+    assert rc == 0
+    return out[:, 0] if out.shape[1] == 1 else out
+
+
+REF_DIR = os.path.join(_HERE, "_ref")
+
+
+def ref_linalg():
+    """oracle/_ref/libref_linalg.so: the reference's unmodified linalg.h behind ref_vec_ops (oracle/Makefile builds it
+    where /root/reference is present); None when it is not on this machine"""
+    p = os.path.join(REF_DIR, "libref_linalg.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    fp = C.POINTER(C.c_float)
+    L.ref_vec_ops.argtypes = [C.c_int, fp, fp, fp, fp, C.c_longlong, fp]
+    return L
+
+
+def ref_stb():
+    """oracle/_ref/libref_stb.so: the reference's unmodified stb_image.h (stbi_loadf / stbi_load with 3 components)"""
+    p = os.path.join(REF_DIR, "libref_stb.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    ip = C.POINTER(C.c_int)
+    L.ref_stbi_loadf_rgb.restype = C.POINTER(C.c_float)
+    L.ref_stbi_loadf_rgb.argtypes = [C.c_char_p, ip, ip, ip]
+    L.ref_stbi_load_rgb.restype = C.POINTER(C.c_ubyte)
+    L.ref_stbi_load_rgb.argtypes = [C.c_char_p, ip, ip, ip]
+    L.ref_stbi_free.argtypes = [C.c_void_p]
+    return L
+
+
+def ref_stb_loadf(L, path):
+    """stbi_loadf(path, &w, &h, &comp, 3) -> (h, w, 3) float32, rows in FILE order (top row first)"""
+    w, h, comp = C.c_int(), C.c_int(), C.c_int()
+    p = L.ref_stbi_loadf_rgb(path.encode(), C.byref(w), C.byref(h), C.byref(comp))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    L.ref_stbi_free(p)
+    return out
+
+
+def ref_stb_load8(L, path):
+    w, h, comp = C.c_int(), C.c_int(), C.c_int()
+    p = L.ref_stbi_load_rgb(path.encode(), C.byref(w), C.byref(h), C.byref(comp))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    L.ref_stbi_free(p)
+    return out

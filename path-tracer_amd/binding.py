@@ -81,7 +81,7 @@ SYMBOLS = [
     "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_destroy", "mipt_scene_exact_reciprocal", "mipt_scene_wide_nodes", "mipt_scene_selfcheck_wide",
     "mipt_context_create", "mipt_context_destroy", "mipt_context_arena_bytes",
     "mipt_trace", "mipt_trace_device", "mipt_trace_device_noalloc", "mipt_occluded", "mipt_eye_rays", "mipt_background",
-    "mipt_selftest_fast_division", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
+    "mipt_selftest_fast_division", "mipt_selftest_vec_ops", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
     "mipt_render_device", "mipt_render", "mipt_context_synchronize", "mipt_context_set_profiling",
     "mipt_context_set_counting", "mipt_context_set_overlap", "mipt_context_get_stats", "mipt_context_reset_stats", "mipt_context_set_traversal",
     "mipt_node_create", "mipt_node_destroy", "mipt_node_num_gpus", "mipt_node_uses_rccl", "mipt_node_render",
@@ -170,6 +170,7 @@ def lib():
     L.mipt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), fp]
     L.mipt_context_synchronize.argtypes = [vp]
     L.mipt_selftest_fast_division.argtypes = [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.mipt_selftest_vec_ops.argtypes = [vp, C.c_int, fp, fp, fp, fp, C.c_size_t, fp]
     L.mipt_buffer_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mipt_buffer_free.argtypes = [vp, vp]
     L.mipt_buffer_zero.argtypes = [vp, vp, C.c_size_t]
@@ -575,6 +576,10 @@ class Context:
         check(lib().mipt_selftest_fast_division(self.h, n_pairs, seed, C.byref(bad)))
         return bad.value
 
+    def vec_ops(self, op, a, b=None, c=None, d=None):
+        """pt/vec.hpp's primitives on this context's GPU (see vec_ops below)"""
+        return vec_ops(op, a, b, c, d, ctx=self)
+
     def buffer_alloc(self, nbytes, zero=True):
         p = C.c_void_p()
         check(lib().mipt_buffer_alloc(self.h, nbytes, C.byref(p)))
@@ -675,3 +680,17 @@ def render_node(scene, cam, ngpus, mode=MODE_PATH, spp=1, sample_offset=0, max_b
     rgb = np.zeros((cam.height, cam.width, 3), np.float32)
     check(lib().mipt_render_node(scene.h, C.byref(cam), C.byref(p), int(ngpus), _fp(rgb)))
     return rgb
+
+
+VEC_OUT_WIDTH = (1, 3, 3, 1, 3, 1, 2, 3)  # floats per element: dot cross normalize det3 mul length2 normalize2 div
+
+
+def vec_ops(op, a, b=None, c=None, d=None, ctx=None):
+    """mipt_selftest_vec_ops: pt/vec.hpp's primitives over (n, 3) float32 arrays; ctx None = the host build"""
+    arrs = [None if x is None else np.ascontiguousarray(x, np.float32).reshape(-1, 3) for x in (a, b, c, d)]
+    n = arrs[0].shape[0]
+    out = np.empty((n, VEC_OUT_WIDTH[op]), np.float32)
+    fp = C.POINTER(C.c_float)
+    ptrs = [x.ctypes.data_as(fp) if x is not None else None for x in arrs]
+    check(lib().mipt_selftest_vec_ops(ctx.h if ctx is not None else None, op, *ptrs, n, out.ctypes.data_as(fp)))
+    return out[:, 0] if out.shape[1] == 1 else out

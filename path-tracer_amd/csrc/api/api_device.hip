@@ -1361,6 +1361,38 @@ int mipt_selftest_fast_division(mipt_ctx* c, uint64_t n_pairs, uint32_t seed, ui
     return MIPT_OK;
 }
 
+int mipt_selftest_vec_ops(mipt_ctx* c, int op, const float* a, const float* b, const float* cc, const float* d, size_t n, float* out) {
+    return guarded("mipt_selftest_vec_ops", [&]() -> int {
+    static const int outW[8] = {1, 3, 3, 1, 3, 1, 2, 3};
+    static const int nIn[8] = {2, 2, 1, 3, 4, 1, 1, 2};
+    if (op < 0 || op > 7) return fail(MIPT_ERR_INVALID, "mipt_selftest_vec_ops: unknown op");
+    if (n && (!a || !out || (nIn[op] > 1 && !b) || (nIn[op] > 2 && !cc) || (nIn[op] > 3 && !d)))
+        return fail(MIPT_ERR_INVALID, "mipt_selftest_vec_ops: null operand");
+    if (n > 0x7fffffffu / 3) return fail(MIPT_ERR_LIMIT, "mipt_selftest_vec_ops: too many elements");
+    if (n == 0) return MIPT_OK;
+    if (!c) {  // the host build of pt/vec.hpp
+        vec_ops_host(op, a, nIn[op] > 1 ? b : nullptr, nIn[op] > 2 ? cc : nullptr, nIn[op] > 3 ? d : nullptr, n, out);
+        return MIPT_OK;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t inBytes = n * 3 * sizeof(float), outBytes = n * (size_t)outW[op] * sizeof(float);
+    int rc;
+    if ((rc = c->sAux.ensure(4 * align256(inBytes))) != MIPT_OK) return rc;
+    if ((rc = c->sAux2.ensure(outBytes)) != MIPT_OK) return rc;
+    const float* src[4] = {a, b, cc, d};
+    float* dv[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < nIn[op]; k++) {
+        dv[k] = (float*)((unsigned char*)c->sAux.p + (size_t)k * align256(inBytes));
+        HIP_TRY(hipMemcpyAsync(dv[k], src[k], inBytes, hipMemcpyHostToDevice, c->stream));
+    }
+    launch_vec_ops(c->stream, op, dv[0], dv[1], dv[2], dv[3], n, (float*)c->sAux2.p);
+    HIP_TRY(hipMemcpyAsync(out, c->sAux2.p, outBytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return MIPT_OK;
+    });
+}
+
 int mipt_trace_device(mipt_ctx* c, const void* rays_dev, size_t n, void* hits_dev) {
     if (!c || (n && (!rays_dev || !hits_dev))) return fail(MIPT_ERR_INVALID, "mipt_trace_device: null argument");
     if (n > 0x7fffffffu) return fail(MIPT_ERR_LIMIT, "mipt_trace_device: at most 2^31-1 rays per call");

@@ -107,6 +107,9 @@ void launch_resolve_hits(hipStream_t st, const DevScene& s, const float4* rays, 
                          float* out);
 void launch_background(hipStream_t st, const DevScene& s, const float* dir, size_t n, float* rgb);
 
+// pt/vec.hpp's primitives over arrays of float3, on the device / on the host (same source, same flags)
+void launch_vec_ops(hipStream_t st, int op, const float* a, const float* b, const float* c, const float* d, size_t n, float* out);
+void vec_ops_host(int op, const float* a, const float* b, const float* c, const float* d, size_t n, float* out);
 void launch_divcheck(hipStream_t st, unsigned seed, unsigned blocks, unsigned perThread, unsigned long long* mismatches);
 
 // integrator (kernels_integrate.hip)

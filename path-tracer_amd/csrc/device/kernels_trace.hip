@@ -394,6 +394,36 @@ void launch_divcheck(hipStream_t st, unsigned seed, unsigned blocks, unsigned pe
     hipLaunchKernelGGL(k_divcheck, dim3(blocks), dim3(kBlock), 0, st, seed, perThread, mismatches);
 }
 
+// pt/vec.hpp's primitives over plain arrays, on the device (mipt_selftest_vec_ops): what tests compare with the
+// reference's own linalg.h bit for bit.  op codes: see include/mipt.h
+__host__ __device__ inline void vec_op_one(int op, const float* a, const float* b, const float* c, const float* d, size_t i, float* out) {
+    const vec3 A{a[3 * i], a[3 * i + 1], a[3 * i + 2]};
+    const vec3 B = b ? vec3{b[3 * i], b[3 * i + 1], b[3 * i + 2]} : vec3{0, 0, 0};
+    const vec3 Cc = c ? vec3{c[3 * i], c[3 * i + 1], c[3 * i + 2]} : vec3{0, 0, 0};
+    const vec3 D = d ? vec3{d[3 * i], d[3 * i + 1], d[3 * i + 2]} : vec3{0, 0, 0};
+    vec3 r{0, 0, 0};
+    switch (op) {
+    case 0: out[i] = pt::dot(A, B); return;
+    case 1: r = pt::cross(A, B); break;
+    case 2: r = pt::normalize(A); break;
+    case 3: out[i] = pt::det3(A, B, Cc); return;
+    case 4: r = pt::mulcols(A, B, Cc, D); break;
+    case 5: out[i] = pt::length2(A); return;
+    case 6: { const pt::vec2 q = pt::normalize(pt::vec2{A.x, A.y}); out[2 * i] = q.x; out[2 * i + 1] = q.y; return; }
+    case 7: r = vec3{A.x / B.x, A.y / B.y, A.z / B.z}; break;
+    default: return;
+    }
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+__global__ __launch_bounds__(kBlock) void k_vec_ops(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                                    const float* __restrict__ c, const float* __restrict__ d, unsigned n,
+                                                    float* __restrict__ out) {
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) vec_op_one(op, a, b, c, d, i, out);
+}
+void vec_ops_host(int op, const float* a, const float* b, const float* c, const float* d, size_t n, float* out) {
+    for (size_t i = 0; i < n; i++) vec_op_one(op, a, b, c, d, i, out);
+}
+
 // The handful of rays per launch that k_trace_wide hands back (a direction component that is exactly zero, mostly)
 // would each keep ONE lane of k_trace walking for a millisecond while the chip waits.  k_trace_slow gives every such
 // ray a whole wavefront instead: the threaded walk (cs488.h:1661-1705) visits a node exactly when its parent's box was
@@ -557,6 +587,9 @@ void launch_eye_rays(hipStream_t st, const CameraDev& cam, size_t first, size_t 
 void launch_resolve_hits(hipStream_t st, const DevScene& s, const float4* rays, const float4* hits, size_t n,
                          float* out) {
     hipLaunchKernelGGL(k_resolve_hits, dim3(grid_for(n)), dim3(kBlock), 0, st, s, rays, hits, (unsigned)n, out);
+}
+void launch_vec_ops(hipStream_t st, int op, const float* a, const float* b, const float* c, const float* d, size_t n, float* out) {
+    hipLaunchKernelGGL(k_vec_ops, dim3(grid_for(n)), dim3(kBlock), 0, st, op, a, b, c, d, (unsigned)n, out);
 }
 void launch_background(hipStream_t st, const DevScene& s, const float* dir, size_t n, float* rgb) {
     hipLaunchKernelGGL(k_background, dim3(grid_for(n)), dim3(kBlock), 0, st, s, dir, (unsigned)n, rgb);

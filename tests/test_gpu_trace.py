@@ -109,16 +109,16 @@ def test_single_triangle_known_answer(B, ob):
 
 @pytest.mark.parametrize("name,w,h", [("cornellbox", 512, 512), ("bunny", 1024, 1024), ("teapot-glass", 1920, 1080)])
 def test_full_size_properties(B, ob, sf, name, w, h):
-    """BASELINE resolutions: hit ids bit-exact on a row subsample against the oracle; device-side eye rays +
-    device trace agree with the host-pointer entry point; hits lie on their triangles"""
+    """BASELINE resolutions (configs[0] is "bit-exact primary hit IDs" at 512x512): ids, t and barycentrics of the
+    WHOLE frame bit-exact against the oracle (every ray, not a subsample: the oracle needs well under a second per
+    frame); hits lie on their triangles; tracing again returns the same bits"""
     scene, ctx, orc = setup_scene(B, sf, name)
     cam = B.default_camera(w, h)
     o, d = ctx.eye_rays(cam)
     tri, t, bary = ctx.trace(o, d)
-    rows = np.arange(0, h, max(1, h // 24))
-    idx = (rows[:, None] * w + np.arange(w)[None, :]).reshape(-1)
-    otri, ot, obary = orc.intersect(o[idx], d[idx])
-    assert np.array_equal(tri[idx], otri) and np.array_equal(bits(t[idx]), bits(ot))
+    assert tri.size == w * h
+    otri, ot, obary = orc.intersect(o, d)
+    assert np.array_equal(tri, otri) and np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(bary), bits(obary))
     # barycentric validity and t window on every hit
     hit = tri >= 0
     assert np.all(t[hit] > 1e-5) and np.all(bary[hit] >= 0) and np.all(bary[hit].sum(axis=1) <= 1.0 + 1e-6)
