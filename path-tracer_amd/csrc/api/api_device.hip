@@ -699,6 +699,8 @@ struct mipt_ctx {
     // 0.1-0.2 ms tail of every traversal launch (MIPT_OVERLAP=0 in the environment turns it off for A/B runs).
     hipStream_t side = nullptr;
     bool overlap = true;
+    bool fuse = true;         // ... or, better, in ONE launch (k_trace_wide_both; MIPT_FUSE=0 goes back to two streams)
+    bool shadowFirst = false; // order of the two queues inside the fused launch (MIPT_FUSE_ORDER=shadow)
     std::vector<hipEvent_t> evShaded, evOccluded;  // per bounce iteration, created on first use (no timing)
     unsigned char* scratch = nullptr;  // this GPU's copy of the file-scope `scratch` array (mipt_trace_device_noalloc)
     bool useWide = true;   // MIPT_TRAVERSAL=walk in the environment forces the literal walk (A/B runs)
@@ -823,6 +825,31 @@ void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueVie
     } else {
         launch_trace_occluded(st, c->ds, rays, target, q, cursor, occ, cnt);
     }
+}
+// path mode, one launch for both traversals of a bounce (kernels_trace_wide.hip: k_trace_wide_both): the extension rays
+// (queue qC, hits) and the shadow rays (queue qO, occ); the rays either body hands back go through the same follow-up
+// launches as after the separate launches.  false: this context / scene cannot (the caller launches them separately)
+bool trace_both(mipt_ctx* c, const float4* raysC, const int* indexC, QueueView qC, unsigned* cursorC, float4* hits,
+                const float4* raysO, const int* targetO, QueueView qO, unsigned* cursorO, unsigned char* occ) {
+#if PT_WIDE_K == 8
+    if (c->useBitTrail || !(c->ds.nWide > 0 && c->useWide)) return false;
+    if (ensure_slow(c, c->slow, qC.space, c->stream) != MIPT_OK || ensure_slow(c, c->slowOcc, qO.space, c->stream) != MIPT_OK) return false;
+    count_launch(c, 0);
+    count_launch(c, 1);
+    unsigned long long* cntC = c->counting ? c->dTotals + 2 : nullptr;
+    unsigned long long* cntO = c->counting ? c->dTotals + 4 : nullptr;
+    unsigned* sc = (unsigned*)c->slow.p;
+    unsigned* so = (unsigned*)c->slowOcc.p;
+    launch_trace_wide_both(c->stream, c->ds, raysC, indexC, qC, cursorC, hits, cntC, sc, (int*)(sc + 2), raysO, targetO, qO, cursorO, occ,
+                           cntO, so, (int*)(so + 2), c->shadowFirst ? 1 : 0);
+    launch_trace_slow_closest(c->stream, c->ds, raysC, indexC, hits, cntC, (const int*)(sc + 2), sc);
+    launch_trace_closest(c->stream, c->ds, raysC, indexC, QueueView{nullptr, 0u, qC.space}, sc + 1, hits, cntC, (const int*)(sc + 2), sc);
+    launch_trace_slow_occluded(c->stream, c->ds, raysO, targetO, occ, cntO, (const int*)(so + 2), so);
+    launch_trace_occluded(c->stream, c->ds, raysO, targetO, QueueView{nullptr, 0u, qO.space}, so + 1, occ, cntO, (const int*)(so + 2), so);
+    return true;
+#else
+    return false;
+#endif
 }
 QueueView dense(size_t n) { return QueueView{nullptr, 0u, (unsigned)n}; }
 
@@ -1132,6 +1159,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
         c->useBitTrail = std::string(tv) == "bittrail" && s->btOk;
     }
     if (const char* ov = getenv("MIPT_OVERLAP")) c->overlap = std::string(ov) != "0";
+    if (const char* fv = getenv("MIPT_FUSE")) c->fuse = std::string(fv) != "0";
+    if (const char* fo = getenv("MIPT_FUSE_ORDER")) c->shadowFirst = std::string(fo) == "shadow";
     if (stream) c->stream = (hipStream_t)stream;
     else {
         if (hipStreamCreate(&c->stream) != hipSuccess) return fail(MIPT_ERR_DEVICE, "hipStreamCreate failed");
@@ -1555,7 +1584,16 @@ int mipt_background(mipt_ctx* c, const float* dir, size_t n, float* rgb) {
 
 // the side stream and one event pair per bounce iteration (created once; events carry no timing)
 static int ensure_side(mipt_ctx* c, int nIter) {
-    if (!c->side) HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    if (!c->side) {
+        // MIPT_SIDE_PRIORITY=high|low (A/B runs): the shadow-ray launches ahead of / behind the extension-ray launch they
+        // run beside, when the hardware has to choose between their blocks
+        int lo = 0, hi = 0;
+        const char* pr = getenv("MIPT_SIDE_PRIORITY");
+        if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            HIP_TRY(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, std::string(pr) == "high" ? hi : lo));
+        else
+            HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    }
     while ((int)c->evShaded.size() < nIter) {
         hipEvent_t a = nullptr, b = nullptr;
         HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -1684,11 +1722,23 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
         // path mode: occluded(it) runs on the side stream beside closest(it+1) (both depend only on shade(it));
         // shade(it+1) waits for both.  Everything the side stream does is waited for on c->stream before this call
         // returns, so the caller's ordering on c->stream holds.
-        const bool overlap = pathMode && c->overlap && !c->useBitTrail && ensure_side(c, lastIter + 1) == MIPT_OK;
+        // ... or, when the scene qualifies for the wide traversal, both in ONE launch (trace_both): occluded(it) is then
+        // deferred to the launch of closest(it+1), and the last one runs alone after the loop
+        const bool fused = pathMode && c->overlap && c->fuse && PT_WIDE_K == 8 && !c->useBitTrail && c->ds.nWide > 0 && c->useWide;
+        const bool overlap = pathMode && c->overlap && !fused && !c->useBitTrail && ensure_side(c, lastIter + 1) == MIPT_OK;
+        bool shadowsOwed = false;  // fused: the shadow rays of bounce it-1 are still to be traced
+        auto shadowQueue = [&](int it) {
+            return QueueView{pb.counters + counter_index(it, 2, 0), pb.regionSize * (unsigned)nl, pb.space * (unsigned)nl};
+        };
         for (int it = 0; it <= lastIter; it++) {
-            trace_closest(c, pb.rays, pb.qExt[it & 1],
-                          QueueView{pb.counters + counter_index(it, 0, 0), pb.regionSize, pb.space},
-                          pb.counters + counter_index(it, 3, 0), pb.hit);
+            const QueueView qExt{pb.counters + counter_index(it, 0, 0), pb.regionSize, pb.space};
+            if (!(shadowsOwed && trace_both(c, pb.rays, pb.qExt[it & 1], qExt, pb.counters + counter_index(it, 3, 0), pb.hit, pb.shRays,
+                                            pb.shTarget, shadowQueue(it - 1), pb.counters + counter_index(it - 1, 4, 0), pb.occ))) {
+                if (shadowsOwed)
+                    trace_occluded(c, pb.shRays, pb.shTarget, shadowQueue(it - 1), pb.counters + counter_index(it - 1, 4, 0), pb.occ, c->stream);
+                trace_closest(c, pb.rays, pb.qExt[it & 1], qExt, pb.counters + counter_index(it, 3, 0), pb.hit);
+            }
+            shadowsOwed = false;
             if (overlap && it > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->evOccluded[(size_t)it - 1], 0));  // shade(it) reads occ of bounce it-1
             {
                 Timer tm(c, 2);
@@ -1696,7 +1746,9 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
                 if (pathMode) launch_shade_path(c->stream, c->ds, fp, pb, it, false);
                 else launch_shade_a(c->stream, c->ds, fp, pb, it);
             }
-            if (rp->mode != MIPT_MODE_PRIMARY) {
+            if (fused) {
+                shadowsOwed = true;
+            } else if (rp->mode != MIPT_MODE_PRIMARY) {
                 hipStream_t occStream = c->stream;
                 if (overlap) {
                     HIP_TRY(hipEventRecord(c->evShaded[(size_t)it], c->stream));
@@ -1726,6 +1778,8 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
                 if (next == 0) break;
             }
         }
+        if (shadowsOwed)  // fused: the shadow rays of the last bounce, alone
+            trace_occluded(c, pb.shRays, pb.shTarget, shadowQueue(itDone - 1), pb.counters + counter_index(itDone - 1, 4, 0), pb.occ, c->stream);
         if (overlap && itDone > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->evOccluded[(size_t)itDone - 1], 0));
         if (rp->mode == MIPT_MODE_PATH) {
             Timer tm(c, 2);

@@ -130,8 +130,14 @@ constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's pe
 #endif
 // LDS of one k_trace_wide block (PT_TUNE_WIDE_PER_CU blocks share a CU's 160 KB): the per-lane stacks (kWideMaxDepth
 // words per lane), the shard prefix sums, and the first kWideTopNodes wide nodes (16 * kWideNodeF4 bytes each)
+// PT_WIDE_SHARE (round 3): once the queue is empty, idle lanes of a wavefront adopt parts of their neighbours' stacks
+// (kernels_trace_wide.hip, "Sharing the tail"); costs 13 bytes of LDS per lane: a byte to pair lanes, an 8-byte merge
+// key and a 4-byte count of helpers still out for the lane's ray
+#ifndef PT_WIDE_SHARE
+#define PT_WIDE_SHARE (PT_WIDE_K == 8)
+#endif
 #ifndef PT_TUNE_WIDE_TOP
-#define PT_TUNE_WIDE_TOP ((163840 / PT_TUNE_WIDE_PER_CU - 320 - 4 * kWideMaxDepth * PT_TUNE_WIDE_BLOCK) / (16 * kWideNodeF4))
+#define PT_TUNE_WIDE_TOP ((163840 / PT_TUNE_WIDE_PER_CU - 640 - (4 * kWideMaxDepth + 13 * PT_WIDE_SHARE) * PT_TUNE_WIDE_BLOCK) / (16 * kWideNodeF4))
 #endif
 constexpr int kWideBlocksPerCU = PT_TUNE_WIDE_PER_CU;
 constexpr int kWideTopNodes = PT_TUNE_WIDE_TOP;

@@ -7,6 +7,7 @@
 // a whole frame is enqueued without host syncs.
 #include "kernels.hpp"
 #include "shading.hpp"
+#include "slow_walk.hpp"
 
 namespace ptd {
 
@@ -76,7 +77,6 @@ constexpr int kPendAnyHit = PT_TUNE_PEND_ANYHIT;  // any-hit rays end at their f
 constexpr unsigned kSlowMaxRays = 4096;  // lists up to this long go to k_trace_slow, longer ones to k_trace
 constexpr int kSlowGrid = 256;           // wavefronts of k_trace_slow (an idle launch costs a few microseconds per 256)
 constexpr int kSlowStack = 8192;         // node stack of one k_trace_slow wavefront (32 KB of LDS)
-constexpr int kSlowReserve = 256;        // ... of which this much is kept free for one-node-at-a-time steps
 
 template <bool ANYHIT, bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s, const float4* __restrict__ rays,
@@ -195,24 +195,26 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                     const unsigned j = chunkBase + rank;  // dense ray index
                     unsigned slot = j;
                     if (remap) {
-                        slot = (unsigned)remap[j];
+                        slot = (unsigned)remap[j];  // -1: a k_trace_wide wavefront has traced this one already
                     } else if (q.counts) {  // dense index -> shard: j < total = prefix[kShards] ends the loop
                         unsigned sh = chunkShard;
                         while (j >= prefix[sh + 1]) ++sh;
                         slot = sh * q.regionSize + (j - prefix[sh]);
                     }
-                    queueSlot = slot;
-                    raySlot = index ? (unsigned)index[slot] : slot;
-                    const size_t rs = ANYHIT ? (size_t)slot : (size_t)raySlot;  // shadow rays live in queue order
-                    const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
-                    ox = r0.x; oy = r0.y; oz = r0.z; tMin = r0.w;
-                    dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
-                    fast = s.planesTame && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz});
-                    yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
-                    bestTri = -1; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
-                    node = 0;
-                    hasRay = true;
-                    walking = true;
+                    if (!(remap && (int)slot < 0)) {
+                        queueSlot = slot;
+                        raySlot = index ? (unsigned)index[slot] : slot;
+                        const size_t rs = ANYHIT ? (size_t)slot : (size_t)raySlot;  // shadow rays live in queue order
+                        const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
+                        ox = r0.x; oy = r0.y; oz = r0.z; tMin = r0.w;
+                        dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
+                        fast = s.planesTame && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz});
+                        yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
+                        bestTri = -1; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
+                        node = 0;
+                        hasRay = true;
+                        walking = true;
+                    }
                 }
                 chunkBase += take;
                 chunkLeft -= take;
@@ -424,16 +426,9 @@ void vec_ops_host(int op, const float* a, const float* b, const float* c, const 
     for (size_t i = 0; i < n; i++) vec_op_one(op, a, b, c, d, i, out);
 }
 
-// The handful of rays per launch that k_trace_wide hands back (a direction component that is exactly zero, mostly)
-// would each keep ONE lane of k_trace walking for a millisecond while the chip waits.  k_trace_slow gives every such
-// ray a whole wavefront instead: the threaded walk (cs488.h:1661-1705) visits a node exactly when its parent's box was
-// hit, so the wavefront keeps a stack of nodes still to be visited, pops up to 64 of them at a time, tests their boxes
-// with the reference's IEEE predicate (NaN quotients included: nothing here relies on nesting), pushes both children
-// of every interior node that was hit and tests the triangles of every leaf that was hit.  Visit order is not the
-// walk's, so ties in t go to the smaller leafTris index, which IS the walk's order (as in k_trace_wide).  Only for
-// trees that build_wide has verified (s.nodeRight exists only then).  The stack cannot overflow: above
-// kSlowStack - kSlowReserve entries a step pops one node, which is a plain depth-first walk and adds at most one
-// entry per level (binary depth <= 96 < kSlowReserve - 128: DevScene::slowOk, checked when the scene is made).
+// The handful of rays per launch that k_trace_wide hands back, a wavefront per ray (slow_walk.hpp), as a launch of its
+// own: since round 3 only for contexts that do not let k_trace_wide's own wavefronts trace them (MIPT_DRAIN=0).
+// Entries that a k_trace_wide wavefront has already taken read -1.
 template <bool ANYHIT, bool COUNT>
 __global__ __launch_bounds__(64) void k_trace_slow(DevScene s, const float4* __restrict__ rays, const int* __restrict__ index,
                                                    const int* __restrict__ target, float4* __restrict__ hits,
@@ -443,71 +438,17 @@ __global__ __launch_bounds__(64) void k_trace_slow(DevScene s, const float4* __r
     const unsigned n = *listCount;
     if (n > kSlowMaxRays || !s.slowOk) return;  // k_trace takes long lists, and every list of a tree too deep for this stack
     const int lane = threadIdx.x;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const __attribute__((address_space(1))) float4v* nodesGlobal = (const __attribute__((address_space(1))) float4v*)s.nodes;
-    const __attribute__((address_space(1))) float4v* trisGlobal = (const __attribute__((address_space(1))) float4v*)s.leafTris;
     unsigned nv = 0, nt = 0;
     for (unsigned r = blockIdx.x; r < n; r += gridDim.x) {
+        if (list[r] < 0) continue;
         const unsigned slot = (unsigned)list[r];
         const unsigned raySlot = index ? (unsigned)index[slot] : slot;
         const size_t rs = ANYHIT ? (size_t)slot : (size_t)raySlot;  // shadow rays live in queue order
         const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
-        const vec3 o{r0.x, r0.y, r0.z}, d{r1.x, r1.y, r1.z};
-        const float tMin = r0.w, tMax = r1.w;
-        int bestTri = -1, bestSeq = 0x7fffffff;
-        float bestT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;
-        int top = 1;
-        if (lane == 0) stack[0] = 0;
-        __syncthreads();
-        while (top > 0) {
-            const int take = top > kSlowStack - kSlowReserve ? 1 : (top < 64 ? top : 64);
-            int node = -1;
-            if (lane < take) node = stack[top - 1 - lane];
-            top -= take;
-            __syncthreads();  // every pop is done before a push reuses its slot
-            int left = 0, right = 0;
-            if (node >= 0) {
-                const float4v n0 = nodesGlobal[2 * (size_t)node], n1 = nodesGlobal[2 * (size_t)node + 1];
-                if (COUNT) nv++;
-                if (slab_hit_ieee(n0, n1, o, d)) {
-                    const int link = f2i(n1.w);
-                    if (link > 0) {
-                        left = link;
-                        right = s.nodeRight[node];
-                    } else {
-                        for (int cur = ~link;; ++cur) {  // the leaf's triangles (cs488.h:1671-1675)
-                            const float4v q0 = trisGlobal[3 * (size_t)cur], q1 = trisGlobal[3 * (size_t)cur + 1],
-                                          q2 = trisGlobal[3 * (size_t)cur + 2];
-                            if (COUNT) nt++;
-                            float t, be, ga;
-                            if (tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z}, o, d, tMin, tMax,
-                                         t, be, ga) &&
-                                (t < bestT || (t == bestT && cur < bestSeq))) {
-                                bestTri = f2i(q0.w); bestSeq = cur; bestT = t; bestB = be; bestG = ga;
-                            }
-                            if (f2i(q1.w)) break;
-                        }
-                    }
-                }
-            }
-            if (ANYHIT && __ballot(bestTri >= 0) != 0ull) break;  // isHit: any accepted triangle decides
-            const unsigned long long mPush = __ballot(left > 0);
-            if (left > 0) {
-                const int at = top + 2 * __popcll(mPush & below);
-                stack[at] = right;
-                stack[at + 1] = left;
-            }
-            top += 2 * __popcll(mPush);
-            __syncthreads();
-        }
-        // the wavefront's answer: smallest t, ties to the smaller leafTris index
-        for (int off = 32; off > 0; off >>= 1) {
-            const float t2 = __shfl_down(bestT, off), b2 = __shfl_down(bestB, off), g2 = __shfl_down(bestG, off);
-            const int tri2 = __shfl_down(bestTri, off), seq2 = __shfl_down(bestSeq, off);
-            if (tri2 >= 0 && (bestTri < 0 || t2 < bestT || (t2 == bestT && seq2 < bestSeq))) {
-                bestTri = tri2; bestSeq = seq2; bestT = t2; bestB = b2; bestG = g2;
-            }
-        }
+        int bestTri, bestSeq;
+        float bestT, bestB, bestG;
+        slow_walk_wave<ANYHIT, COUNT, 64>(s, vec3{r0.x, r0.y, r0.z}, vec3{r1.x, r1.y, r1.z}, r0.w, r1.w, stack, kSlowStack, lane, bestTri,
+                                          bestSeq, bestT, bestB, bestG, nv, nt);
         if (lane == 0) {
             if (ANYHIT) {
                 if (bestTri >= 0) occ[target ? (unsigned)target[slot] : slot] = 1;
@@ -515,7 +456,7 @@ __global__ __launch_bounds__(64) void k_trace_slow(DevScene s, const float4* __r
                 hits[raySlot] = make_float4(i2f(bestTri), bestT, bestB, bestG);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) {

@@ -263,36 +263,126 @@ constexpr unsigned kPendMask = 15u;
 #define PT_GROUP_TAKE group_take
 #endif
 
+#ifndef PT_WIDE_POOL
+#define PT_WIDE_POOL 1  // rays reach the wavefronts through a pool per BLOCK in LDS (below: "The block's pool"); 0: one chunk per wavefront from the global cursor
+#endif
+#ifndef PT_TUNE_WIDE_POOL_MIN
+#define PT_TUNE_WIDE_POOL_MIN 256u    // smallest / largest chunk a block asks the launch's cursor for
+#endif
+#ifndef PT_TUNE_WIDE_POOL_SHIFT
+#define PT_TUNE_WIDE_POOL_SHIFT 1     // a block asks for its share of what is left, shifted right by this
+#endif
+#ifndef PT_TUNE_WIDE_POOL_MAX
+#define PT_TUNE_WIDE_POOL_MAX 8192u
+#endif
+#ifndef PT_TUNE_WIDE_SHARE_MIN
+#define PT_TUNE_WIDE_SHARE_MIN 4  // idle lanes before a hand-over round is worth its instructions (tail of a launch only)
+#endif
 #ifndef PT_DIAG_UTIL
 #define PT_DIAG_UTIL 0  // diagnostic builds only: 1 / 2 turn the counters into lanes-active / lanes-issued of the visit / leaf phase
 #endif
 #define PT_WIDE_ATTR __attribute__((amdgpu_waves_per_eu(WideCfg<ANYHIT>::kWaves, WideCfg<ANYHIT>::kWaves)))
 
-template <bool ANYHIT, bool COUNT>
-__global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_wide(
-    DevScene s, const float4* __restrict__ rays, const int* __restrict__ index, const int* __restrict__ target,
-    QueueView q, unsigned* __restrict__ cursor, float4* __restrict__ hits, unsigned char* __restrict__ occ,
-    unsigned long long* __restrict__ counters, unsigned* __restrict__ slowCount, int* __restrict__ slowList) {
-    constexpr int kBlk = WideCfg<ANYHIT>::kBlock;  // threads per block; shadows nothing: the launchers use the same WideCfg
-    __shared__ float4 top[kWideNodeF4 * WideCfg<ANYHIT>::kTop];
-    __shared__ unsigned stackLds[kWideMaxDepth * kBlk];  // entry d of lane t at [d * kBlk + t]
-    __shared__ unsigned prefix[kShards + 1];
-    const int lane = threadIdx.x & 63;
-    const int nTop = s.nWideTop < WideCfg<ANYHIT>::kTop ? s.nWideTop : WideCfg<ANYHIT>::kTop;
-    for (int i = threadIdx.x; i < kWideNodeF4 * nTop; i += kBlk)  // packed in LDS, kWideNodeStrideF4 apart in the arena
+#ifndef PT_DIAG_TAIL
+#define PT_DIAG_TAIL 0  // diagnostic builds only (tools/tail_diag.py): wall-clock stamps of every wavefront's start, queue-empty moment and end
+#endif
+#if PT_DIAG_TAIL
+// per wavefront of the last closest-hit launch: {start, queue-empty, end, hand-overs} (plain stores: atomics on a few words
+// from 4,096 wavefronts would themselves stretch the launch)
+__device__ unsigned long long g_tailDiag[4 * 4096];
+#endif
+
+// LDS of one block, declared by the kernels and handed to the body (a body inlined twice must not declare it twice)
+struct WideLds {
+    float4* top;                  // the first nTop wide nodes, packed (kWideNodeF4 float4 each)
+    unsigned* stack;              // per-lane stacks: entry d of lane t at [d * block + t]
+    const unsigned* prefix;       // prefix sums over the queue's 64 shard counts (kShards + 1 words)
+    unsigned char* pair;          // hand-over round: rank of a giver -> its lane
+    unsigned long long* key;      // per owner lane: min over its helpers of t << 32 | index
+    unsigned* out;                // per owner lane: helpers still out | failed << 31
+    unsigned long long* pool;     // the block's pool of rays: next dense index << 32 | end of the chunk
+    unsigned* poolCtl;            // [0] lock of the one wavefront that refills the pool, [1] the launch's queue is empty
+};
+#define PT_WIDE_LDS_DECL(KBLK, KTOP)                                                                       \
+    __shared__ float4 ldsTop[kWideNodeF4 * (KTOP)];                                                        \
+    __shared__ unsigned ldsStack[kWideMaxDepth * (KBLK)];                                                  \
+    __shared__ unsigned ldsPrefix[2][kShards + 1];                                                         \
+    __shared__ unsigned char ldsPair[(PT_WIDE_SHARE && PT_WIDE_K == 8) ? (KBLK) : 1];                      \
+    __shared__ unsigned long long ldsKey[(PT_WIDE_SHARE && PT_WIDE_K == 8) ? (KBLK) : 1];                  \
+    __shared__ unsigned ldsOut[(PT_WIDE_SHARE && PT_WIDE_K == 8) ? (KBLK) : 1];                            \
+    __shared__ unsigned long long ldsPool[2];                                                              \
+    __shared__ unsigned ldsPoolCtl[2][2]
+// the top of the tree into LDS (packed there, kWideNodeStrideF4 apart in the arena)
+__device__ __forceinline__ void wide_load_top(const DevScene& s, float4* top, int nTop, int kBlk) {
+    for (int i = threadIdx.x; i < kWideNodeF4 * nTop; i += kBlk)
         top[i] = s.wnodes[(i / kWideNodeF4) * kWideNodeStrideF4 + i % kWideNodeF4];
+}
+// static first chunks: a wavefront's share of three quarters of the queue, 64 .. 1024 rays (see "The queue cursor" in the body)
+__device__ __forceinline__ unsigned wide_static_chunk(unsigned total, unsigned nWaves) {
+    const unsigned c0 = ((total - (total >> PT_TUNE_WIDE_STATIC_SHIFT)) / nWaves) & ~63u;
+    return c0 < 64u ? 64u : (c0 > 1024u ? 1024u : c0);
+}
+// inclusive scan over a sharded queue's 64 counts and the block's pool with its static first chunk, by the block's
+// wavefront `wave`
+__device__ __forceinline__ void wide_prefix(const QueueView& q, unsigned* prefix, int wave, unsigned long long* pool, unsigned* poolCtl,
+                                            int wavesPerBlock) {
+    if ((int)(threadIdx.x >> 6) != wave) return;
+    const int lane = threadIdx.x & 63;
+    unsigned total = q.space;
     if (q.counts) {
-        if (threadIdx.x < 64) {
-            unsigned v = q.counts[(size_t)lane * kCntStride];
-            for (int off = 1; off < 64; off <<= 1) {  // inclusive scan over the 64 shard counts
-                const unsigned up = __shfl_up(v, off);
-                if (lane >= off) v += up;
-            }
-            prefix[lane + 1] = v;
-            if (lane == 0) prefix[0] = 0;
+        unsigned v = q.counts[(size_t)lane * kCntStride];
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned up = __shfl_up(v, off);
+            if (lane >= off) v += up;
         }
+        prefix[lane + 1] = v;
+        if (lane == 0) prefix[0] = 0;
+        total = (unsigned)__shfl((int)v, 63);
     }
-    __syncthreads();
+    if (lane == 0) {  // block b owns rays [b C0, (b + 1) C0), C0 = its wavefronts' static chunks together
+        const unsigned long long C0 = (unsigned long long)wide_static_chunk(total, gridDim.x * (unsigned)wavesPerBlock) * (unsigned)wavesPerBlock;
+        const unsigned long long first = (unsigned long long)blockIdx.x * C0;
+        const unsigned base = first < (unsigned long long)total ? (unsigned)first : total;
+        const unsigned len = (unsigned long long)(total - base) < C0 ? (total - base) : (unsigned)C0;
+        *pool = ((unsigned long long)base << 32) | (unsigned long long)(base + len);
+        poolCtl[0] = 0u;
+        poolCtl[1] = (unsigned long long)gridDim.x * C0 >= (unsigned long long)total ? 1u : 0u;  // nothing behind the static chunks
+    }
+}
+
+template <bool ANYHIT, bool COUNT>
+__device__ __forceinline__ void wide_body(
+    const DevScene& s, const float4* __restrict__ rays, const int* __restrict__ index, const int* __restrict__ target,
+    const QueueView q, unsigned* __restrict__ cursor, float4* __restrict__ hits, unsigned char* __restrict__ occ,
+    unsigned long long* __restrict__ counters, unsigned* __restrict__ slowCount, int* __restrict__ slowList, const WideLds lds) {
+    constexpr int kBlk = WideCfg<ANYHIT>::kBlock;  // threads per block; shadows nothing: the launchers use the same WideCfg
+    float4* const top = lds.top;
+    unsigned* const stackLds = lds.stack;
+    const unsigned* const prefix = lds.prefix;
+    // Sharing the tail (PT_WIDE_SHARE).  A launch ends with every wavefront draining the rays it still holds: lanes fall
+    // idle one by one while the longest ray of the 64 walks on alone -- 0.1 to 0.2 ms per launch in which the chip does
+    // next to nothing, ten times per frame.  The traversal is ORDER-FREE (see the top of this file): the answer is the
+    // smallest accepted t over the admitted leaves, ties to the smaller leafTris index, however the leaves are found --
+    // so they may as well be found by SEVERAL lanes.  Once the queue is empty, an idle lane adopts the bottom entry of
+    // a busy lane's stack (the pending children of the shallowest node that lane still owes a visit: its largest piece
+    // of work), loads the same ray and walks that part on its own, with its own unverified best and its own verdicts.
+    //  * any hit: nothing to merge -- whichever lane finds an admitted, accepted triangle sets the ray's flag.
+    //  * closest hit: a helper that has walked its part folds (t, leafTris index) into the owner's 64-bit key in LDS
+    //    with an atomic minimum (t > 0, so the float's bits order like the number; the index in the low word is the
+    //    reference's tie-break) and counts itself off; the owner writes the hit once its own walk is over and no
+    //    helper is out.  If a helper's triangle wins, the owner tests that one triangle again to get beta and gamma
+    //    (same operands, same instructions, same bits).  A failed verdict anywhere (deferred admission, below) marks
+    //    the ray, and the owner hands it to the exact walk as before.
+    // Lanes of one wavefront run in lockstep and its LDS operations complete in program order, so no more than the
+    // compiler's ordering is needed.  The COUNT instantiations do not share: their visit counts stay a function of the
+    // ray alone.
+    constexpr bool SHARE = PT_WIDE_SHARE && (PT_WIDE_K == 8) && !COUNT;
+    unsigned char* const pairLds = lds.pair;
+    unsigned long long* const shareKey = lds.key;
+    unsigned* const shareOut = lds.out;
+    const int lane = threadIdx.x & 63;
+    const unsigned waveBase = threadIdx.x & ~63u;
+    const int nTop = s.nWideTop < WideCfg<ANYHIT>::kTop ? s.nWideTop : WideCfg<ANYHIT>::kTop;
     const unsigned total = q.counts ? prefix[kShards] : q.space;
     const __attribute__((address_space(3))) float4v* topLds = (const __attribute__((address_space(3))) float4v*)top;
     const __attribute__((address_space(1))) float4v* nodesGlobal = (const __attribute__((address_space(1))) float4v*)s.wnodes;
@@ -304,6 +394,8 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
     unsigned tos = 0;       // top of the stack of interior groups (0: none); older entries in stack[0..sp)
     __attribute__((address_space(3))) unsigned* stack = (__attribute__((address_space(3))) unsigned*)stackLds + threadIdx.x;
     int sp = 0;  // in units of kBlk entries
+    int bot = 0;   // bottom of the stack, same units: entries below it were given to helpers (PT_WIDE_SHARE)
+    int role = -1; // -1: the lane owns its ray alone | -2: owns it and has given parts away | >= 0: helps that lane of this wavefront
     // leaf groups still to be opened (LIFO, g[0] on top; order is free) and the open leaf's triangle cursor
     int groups = 0;
     unsigned g[kWideGroups] = {};  // compile-time indices only: registers
@@ -351,18 +443,36 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
     // chunks at the 64-ray floor) = 0.2 ms of its 0.34 ms the same way.
     const unsigned nWaves = gridDim.x * (unsigned)(kBlk / 64);
     const unsigned gw = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (unsigned)(kBlk / 64) + (threadIdx.x >> 6)));
-    unsigned c0 = ((total - (total >> PT_TUNE_WIDE_STATIC_SHIFT)) / nWaves) & ~63u;
-    c0 = c0 < 64u ? 64u : (c0 > 1024u ? 1024u : c0);
+    (void)gw;
+    const unsigned c0 = wide_static_chunk(total, nWaves);
     const unsigned long long staticAll = (unsigned long long)nWaves * c0;
     const unsigned dynBase = staticAll < (unsigned long long)total ? (unsigned)staticAll : total;  // cursor value 0 = this ray
+    // The block's pool (PT_WIDE_POOL, round 3).  With a chunk per WAVEFRONT the end of a launch is ragged: the wavefront
+    // that took the last 128-ray chunk works on it for two ray-times after the first wavefront has found the queue empty
+    // (measured on a 4 M-ray launch, tools/tail_diag.py: queue-empty moments spread over 75 us, ends over 73 us, the median
+    // wavefront done 48 us before the last), and smaller chunks run into the cursor's 12 ns per atomic.  Now the cursor
+    // feeds a pool per BLOCK in LDS (one word: next index << 32 | end), a wavefront takes exactly as many rays as it has
+    // empty lanes with one LDS atomic, and the ONE wavefront that finds the pool empty and wins the block's lock asks the
+    // cursor for the next chunk (guided: half the block's share of what is left, PT_TUNE_WIDE_POOL_MIN .. _MAX) while the
+    // others walk on: a sixteenth of the global atomics, chunks down to 16 rays per wavefront at the end.  The lock's
+    // holder never waits for anything but its own atomic, so every wavefront reaches the end of the queue.
+    unsigned long long* const pool = lds.pool;
+    unsigned* const poolCtl = lds.poolCtl;
+#if !PT_WIDE_POOL
     {
         const unsigned long long first = (unsigned long long)gw * c0;
         chunkBase = first < (unsigned long long)total ? (unsigned)first : total;
         chunkLeft = (total - chunkBase) < c0 ? (total - chunkBase) : c0;
         if (q.counts && chunkLeft != 0) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= chunkBase));
     }
+#endif
     unsigned lastBase = dynBase;
-    bool exhausted = (chunkLeft == 0 && dynBase >= total);
+    bool exhausted = PT_WIDE_POOL ? (total == 0u) : (chunkLeft == 0 && dynBase >= total);
+#if PT_DIAG_TAIL
+    const unsigned long long diagStart = wall_clock64();
+    unsigned long long diagEmpty = exhausted ? diagStart : 0ull;
+    unsigned diagGifts = 0;
+#endif
 
 #define PT_FINISH()                                                                        \
     do {                                                                                   \
@@ -375,21 +485,77 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
             if (bestSeq != 0x7fffffff) id = f2i(s.leafTris[3 * (size_t)bestSeq].w);        \
             hits[raySlot] = make_float4(i2f(id), bestT, bestB, bestG);                     \
         }                                                                                  \
+        PT_RESET_LANE();                                                                   \
+    } while (0)
+#define PT_RESET_LANE()                                                                    \
+    do {                                                                                   \
         hasRay = false;                                                                    \
         w = -1;                                                                            \
         tos = 0;                                                                           \
         sp = 0;                                                                            \
+        bot = 0;                                                                           \
+        role = -1;                                                                         \
         groups = 0;                                                                        \
         cur = -1;                                                                          \
         uLeaf = -1;                                                                        \
     } while (0)
+// the lane's walk is over: nothing to visit, nothing parked, nothing unverified
+#define PT_WALK_OVER() (hasRay && w < 0 && groups == 0 && cur < 0 && uLeaf < 0)
 
     while (true) {
         const unsigned long long mEmpty = __ballot(!hasRay);
         const int nEmpty = __popcll(mEmpty);
         if (nEmpty == 64 && exhausted) break;
+        bool fresh = false, adopt = false;  // this lane takes a ray from the queue / a piece of a neighbour's ray
+        unsigned adoptEntry = 0u;
+        int adoptMeta = 0;
         if (!exhausted && nEmpty >= (ANYHIT ? PT_TUNE_WIDE_REFILL_ANYHIT : PT_TUNE_WIDE_REFILL)) {
             // ---- refill: empty lanes take the next rays of the queue ----
+#if PT_WIDE_POOL
+            {
+                unsigned long long old = 0ull;
+                if (lane == 0) old = __hip_atomic_fetch_add(pool, (unsigned long long)(unsigned)nEmpty << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned cur = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32));
+                const unsigned end = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
+                chunkLeft = 0u;
+                if (cur < end) {  // (the index half may have run past the end while the pool stood empty: that is "empty" too)
+                    chunkBase = cur;
+                    chunkLeft = (end - cur) < (unsigned)nEmpty ? (end - cur) : (unsigned)nEmpty;
+                    lastBase = cur > dynBase ? cur : dynBase;  // how far the CURSOR has come, as far as this wavefront knows
+                    if (q.counts) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= cur));
+                } else {
+                    int state = 0;  // 1: the launch's queue is empty, 2: this wavefront refills the pool
+                    if (lane == 0) {
+                        if (__hip_atomic_load(&poolCtl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) state = 1;
+                        else if (atomicCAS(&poolCtl[0], 0u, 1u) == 0u) state = 2;
+                    }
+                    state = __builtin_amdgcn_readfirstlane(state);
+                    if (state == 1) {
+                        exhausted = true;
+#if PT_DIAG_TAIL
+                        diagEmpty = wall_clock64();
+#endif
+                    } else if (state == 2) {
+                        if (lane == 0) {
+                            const unsigned long long now = __hip_atomic_load(pool, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            // (another wavefront may have refilled it between this one's look and its lock)
+                            if ((unsigned)(now >> 32) >= (unsigned)now && __hip_atomic_load(&poolCtl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                                unsigned chunkRays = (((total - lastBase) / gridDim.x) >> PT_TUNE_WIDE_POOL_SHIFT) & ~63u;
+                                chunkRays = chunkRays < PT_TUNE_WIDE_POOL_MIN ? PT_TUNE_WIDE_POOL_MIN : (chunkRays > PT_TUNE_WIDE_POOL_MAX ? PT_TUNE_WIDE_POOL_MAX : chunkRays);
+                                const unsigned b = atomicAdd(cursor, chunkRays);
+                                if (b >= total - dynBase) {
+                                    __hip_atomic_store(&poolCtl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                } else {
+                                    const unsigned nb = dynBase + b, len = (total - nb) < chunkRays ? (total - nb) : chunkRays;
+                                    __hip_atomic_store(pool, ((unsigned long long)nb << 32) | (unsigned long long)(nb + len), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                            }
+                            __hip_atomic_store(&poolCtl[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
+#else
             if (chunkLeft == 0) {
                 unsigned base = total;
                 unsigned chunkRays = ((total - lastBase) / (nWaves * 2u)) & ~63u;
@@ -401,6 +567,9 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                 }
                 if (base >= total) {
                     exhausted = true;
+#if PT_DIAG_TAIL
+                    diagEmpty = wall_clock64();
+#endif
                 } else {
                     chunkBase = base;
                     lastBase = base;
@@ -408,14 +577,13 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                     if (q.counts) chunkShard = (unsigned)__popcll(__ballot(prefix[lane + 1] <= base));
                 }
             }
+#endif
             if (chunkLeft != 0) {
                 const unsigned rank = (unsigned)__popcll(mEmpty & ((1ull << lane) - 1ull));
                 const unsigned take = chunkLeft < (unsigned)nEmpty ? chunkLeft : (unsigned)nEmpty;
-                bool slow = false;
-                unsigned slot = 0;
                 if (!hasRay && rank < take) {
                     const unsigned j = chunkBase + rank;  // dense ray index
-                    slot = j;
+                    unsigned slot = j;
                     if (q.counts) {  // dense index -> shard: j < total = prefix[kShards] ends the loop
                         unsigned sh = chunkShard;
                         while (j >= prefix[sh + 1]) ++sh;
@@ -423,11 +591,81 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                     }
                     queueSlot = slot;
                     raySlot = index ? (unsigned)index[slot] : slot;
-                    const size_t rs = ANYHIT ? (size_t)slot : (size_t)raySlot;  // shadow rays live in queue order
+                    fresh = true;
+                }
+                chunkBase += take;
+                chunkLeft -= take;
+            }
+        } else if (SHARE && exhausted && nEmpty >= PT_TUNE_WIDE_SHARE_MIN && nEmpty < 64) {
+            // ---- the tail: idle lanes adopt the bottom stack entries of busy ones ("Sharing the tail" above) ----
+            // what a busy lane can spare: the bottom entry of its stack (the pending children of the shallowest node it
+            // still owes a visit: its largest piece), else the pending siblings of the node it is about to visit, else
+            // its oldest parked leaf group when something else keeps it busy
+            int giveKind = 0;  // 1: interior entry, 2: leaf group
+            if (hasRay && !(ANYHIT && uLeaf >= 0)) {
+                if (sp > bot || (tos != 0u && w >= 0)) giveKind = 1;
+                else if (groups >= 2 || (groups == 1 && (w >= 0 || cur >= 0))) giveKind = 2;
+            }
+            const unsigned long long mGive = __ballot(giveKind != 0);
+            if (mGive != 0ull) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int nGive = __popcll(mGive);
+                const int nPairs = nGive < nEmpty ? nGive : nEmpty;
+                const int rankG = __popcll(mGive & below), rankE = __popcll(mEmpty & below);
+                unsigned gEntry = 0u;
+                int gMeta = 0;  // (owner lane + 1) | kind << 8
+                if (giveKind != 0 && rankG < nPairs) {
+                    if (giveKind == 1) {
+                        if (sp > bot) { gEntry = stack[bot]; bot += kBlk; }
+                        else { gEntry = tos; tos = 0u; }
+                    } else {
+                        gEntry = groups >= 4 ? g[kWideGroups - 1] : (groups == 3 ? g[2] : (groups == 2 ? g[1] : g[0]));
+                        --groups;
+                    }
+                    pairLds[waveBase + (unsigned)rankG] = (unsigned char)lane;
+                    int root = -1;
+                    if (!ANYHIT) {
+                        if (role == -1) {  // first piece this lane gives away: its merge slot starts empty
+                            role = -2;
+                            shareKey[threadIdx.x] = ~0ull;
+                            shareOut[threadIdx.x] = 0u;
+                        }
+                        root = role >= 0 ? role : lane;  // a helper gives on behalf of the lane it helps
+                        __hip_atomic_fetch_add(&shareOut[waveBase + (unsigned)root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                    gMeta = (root + 1) | (giveKind << 8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if PT_DIAG_TAIL
+                diagGifts += (unsigned)nPairs;
+#endif
+                const bool takes = !hasRay && rankE < nPairs;
+                int src = lane;
+                if (takes) src = (int)pairLds[waveBase + (unsigned)rankE];
+                const unsigned gotEntry = (unsigned)__shfl((int)gEntry, src);
+                const unsigned gotQueue = (unsigned)__shfl((int)queueSlot, src), gotRay = (unsigned)__shfl((int)raySlot, src);
+                const int gotMeta = __shfl(gMeta, src);
+                if (takes) {
+                    adoptEntry = gotEntry;
+                    queueSlot = gotQueue;
+                    raySlot = gotRay;
+                    adoptMeta = gotMeta;
+                    adopt = true;
+                }
+            }
+        }
+        if (__ballot(fresh || adopt) != 0ull) {
+            {
+                bool slow = false;
+                if (fresh || adopt) {
+                    const size_t rs = ANYHIT ? (size_t)queueSlot : (size_t)raySlot;  // shadow rays live in queue order
                     const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
                     ox = r0.x; oy = r0.y; oz = r0.z; tMin = r0.w;
                     dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
-                    if (!s.handBackAll && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz})) {
+                    // (an adopted ray qualified when its owner took it from the queue)
+                    if (adopt || (!s.handBackAll && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz}))) {
                         yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
 #if PT_TUNE_WIDE_FMA
                         ynx = yx * 0x1.ffffcp-1f; yny = yy * 0x1.ffffcp-1f; ynz = yz * 0x1.ffffcp-1f;
@@ -460,6 +698,21 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
 #endif
                         bestTri = -1; bestSeq = 0x7fffffff; bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
                         w = 0;
+                        sp = 0; bot = 0; role = -1; tos = 0u;
+#if PT_WIDE_K == 8
+                        if (SHARE && adopt) {
+                            if ((adoptMeta >> 8) == 1) {  // a helper starts at the first pending child of the entry it was given
+                                tos = adoptEntry;
+                                w = group_take8(tos);
+                                if ((tos & 255u) == 0u) tos = 0u;
+                            } else {  // ... or with the leaf group it was given
+                                w = -1;
+                                g[0] = adoptEntry;
+                                groups = 1;
+                            }
+                            if (!ANYHIT) role = (adoptMeta & 255) - 1;
+                        }
+#endif
                         hasRay = true;
                     } else if (ox != ox || oy != oy || oz != oz || dx != dx || dy != dy || dz != dz) {
                         // A NaN anywhere in the ray: every determinant of raytraceTriangle that decides acceptance
@@ -476,13 +729,11 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                     unsigned at = 0;
                     if (lane == 0) at = atomicAdd(slowCount, (unsigned)__popcll(mSlow));
                     at = __shfl(at, 0);
-                    if (slow) slowList[at + (unsigned)__popcll(mSlow & ((1ull << lane) - 1ull))] = (int)slot;
+                    if (slow) slowList[at + (unsigned)__popcll(mSlow & ((1ull << lane) - 1ull))] = (int)queueSlot;
                 }
-                chunkBase += take;
-                chunkLeft -= take;
             }
-            if (nEmpty == 64) continue;  // nothing else to do yet
         }
+        if (nEmpty == 64) continue;  // nothing else to do yet (the refill may have found rays: look again)
         // ---- visits: lanes with a node to visit and room for one more leaf group ----
 #pragma unroll
         for (int b = 0; b < (ANYHIT ? PT_TUNE_WIDE_BURST_ANYHIT : PT_TUNE_WIDE_BURST); b++) {
@@ -542,7 +793,7 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                     w = group_take8(tos);
                     if ((tos & 255u) == 0u) {
                         tos = 0u;
-                        if (sp > 0) { sp -= kBlk; tos = stack[sp]; }
+                        if (sp > bot) { sp -= kBlk; tos = stack[sp]; }
                     }
                 }
             }
@@ -627,13 +878,13 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                     w = group_take(tos);
                     if ((tos & 15u) == 0u) {
                         tos = 0u;
-                        if (sp > 0) { sp -= kBlk; tos = stack[sp]; }
+                        if (sp > bot) { sp -= kBlk; tos = stack[sp]; }
                     }
                 }
             }
         }
 #endif  // PT_WIDE_K
-        if (hasRay && w < 0 && groups == 0 && cur < 0 && uLeaf < 0) PT_FINISH();  // walked everything, nothing parked, nothing unverified
+        if (PT_WALK_OVER() && (!SHARE || ANYHIT || role == -1)) PT_FINISH();  // walked everything, nothing parked, nothing unverified (lanes that share a ray: at the end of the iteration)
         // ---- leaves: open parked leaves with the exact box test, test their triangles ----
         const unsigned long long mCanVisit = __ballot(w >= 0 && groups < kWideGroups);
         unsigned long long mPend = __ballot(cur >= 0 || groups > 0);
@@ -714,15 +965,69 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
                     else bestTri = -1;      // that triangle does not count; the search goes on
                 } else if (!pass) {
                     // the filtering since that candidate may have dropped the true winner: trace this ray again, exactly
-                    unsigned at = atomicAdd(slowCount, 1u);
-                    slowList[at] = (int)queueSlot;
-                    hasRay = false; w = -1; tos = 0; sp = 0; groups = 0; cur = -1;
+                    if (!SHARE || role == -1) {
+                        unsigned at = atomicAdd(slowCount, 1u);
+                        slowList[at] = (int)queueSlot;
+                        PT_RESET_LANE();
+                    } else if (role >= 0) {  // a helper: mark the owner's ray, count off, fall idle
+                        __hip_atomic_fetch_or(&shareOut[waveBase + (unsigned)role], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        __hip_atomic_fetch_sub(&shareOut[waveBase + (unsigned)role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        PT_RESET_LANE();
+                    } else {  // the owner of a shared ray: mark it, drop what is left of its own walk, wait for the helpers
+                        __hip_atomic_fetch_or(&shareOut[threadIdx.x], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        w = -1; tos = 0u; sp = bot; groups = 0; cur = -1; bestSeq = 0x7fffffff;
+                    }
                 }
             }
-            if (hasRay && w < 0 && groups == 0 && cur < 0) PT_FINISH();
+            if (PT_WALK_OVER() && (!SHARE || ANYHIT || role == -1)) PT_FINISH();
+        }
+        if (SHARE && !ANYHIT && exhausted && PT_WALK_OVER()) {  // only lanes that share a ray get here with their walk over
+            if (role >= 0) {
+                // a helper has walked its part: fold its best into the owner's key (its verdicts are in: uLeaf < 0), count off
+                if (bestSeq != 0x7fffffff)
+                    __hip_atomic_fetch_min(&shareKey[waveBase + (unsigned)role], ((unsigned long long)(unsigned)f2i(bestT) << 32) | (unsigned)bestSeq,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_sub(&shareOut[waveBase + (unsigned)role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                PT_RESET_LANE();
+            } else if (role == -2) {
+                const unsigned out = __hip_atomic_load(&shareOut[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if ((out & 0x7fffffffu) == 0u) {  // every helper has reported
+                    if (out != 0u) {  // some verdict failed: the exact walk traces this ray again
+                        unsigned at = atomicAdd(slowCount, 1u);
+                        slowList[at] = (int)queueSlot;
+                        PT_RESET_LANE();
+                    } else {
+                        const unsigned long long theirs = __hip_atomic_load(&shareKey[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        const unsigned long long mine = bestSeq != 0x7fffffff ? (((unsigned long long)(unsigned)f2i(bestT) << 32) | (unsigned)bestSeq) : ~0ull;
+                        if (theirs < mine) {
+                            // a helper's triangle wins: t and the index are in the key; beta and gamma come from testing that
+                            // one triangle again (same operands, same instructions: the bits the helper had)
+                            bestSeq = (int)(unsigned)(theirs & 0xffffffffull);
+                            const __attribute__((address_space(1))) float4v* triAt =
+                                (const __attribute__((address_space(1))) float4v*)s.leafTris + 3 * (size_t)bestSeq;
+                            const float4v q0 = triAt[0], q1 = triAt[1], q2 = triAt[2];
+                            float t = 0.0f, be = 0.0f, ga = 0.0f;
+                            (void)tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z}, vec3{ox, oy, oz},
+                                           vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
+                            bestT = t; bestB = be; bestG = ga;
+                        }
+                        PT_FINISH();
+                    }
+                }
+            }
         }
     }
 #undef PT_FINISH
+#undef PT_RESET_LANE
+#undef PT_WALK_OVER
+#if PT_DIAG_TAIL
+    if (lane == 0 && !ANYHIT && gw < 4096u) {
+        g_tailDiag[4 * gw] = diagStart;
+        g_tailDiag[4 * gw + 1] = diagEmpty;
+        g_tailDiag[4 * gw + 2] = wall_clock64();
+        g_tailDiag[4 * gw + 3] = diagGifts;
+    }
+#endif
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) {  // wave-level reduction, one atomic pair per wavefront
             nv += __shfl_down(nv, off);
@@ -734,6 +1039,54 @@ __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_
         }
     }
 }
+
+template <bool ANYHIT, bool COUNT>
+__global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_wide(
+    DevScene s, const float4* __restrict__ rays, const int* __restrict__ index, const int* __restrict__ target,
+    QueueView q, unsigned* __restrict__ cursor, float4* __restrict__ hits, unsigned char* __restrict__ occ,
+    unsigned long long* __restrict__ counters, unsigned* __restrict__ slowCount, int* __restrict__ slowList) {
+    PT_WIDE_LDS_DECL(WideCfg<ANYHIT>::kBlock, WideCfg<ANYHIT>::kTop);
+    const int nTop = s.nWideTop < WideCfg<ANYHIT>::kTop ? s.nWideTop : WideCfg<ANYHIT>::kTop;
+    wide_load_top(s, ldsTop, nTop, WideCfg<ANYHIT>::kBlock);
+    wide_prefix(q, ldsPrefix[0], 0, &ldsPool[0], ldsPoolCtl[0], WideCfg<ANYHIT>::kBlock / 64);
+    __syncthreads();
+    wide_body<ANYHIT, COUNT>(s, rays, index, target, q, cursor, hits, occ, counters, slowCount, slowList,
+                             WideLds{ldsTop, ldsStack, ldsPrefix[0], ldsPair, ldsKey, ldsOut, &ldsPool[0], ldsPoolCtl[0]});
+}
+
+#if PT_WIDE_K == 8
+// Both traversals of a bounce in ONE launch (path mode): the extension rays of bounce it + 1 and the shadow rays of
+// bounce it depend only on shade(it), and as two launches each ends in its own tail -- a stretch of 0.1 ms in which a
+// few wavefronts finish their longest rays while the chip idles (two streams did not help: the blocks of the second
+// kernel need whole CUs, which the first gives up only as its own blocks end).  Here a wavefront that has drained the
+// first queue goes straight on to the second: same block, same top of the tree in LDS, one tail per bounce instead of
+// two.  The bodies are the two instantiations above, unchanged; each has its own queue, cursor and hand-back list.
+static_assert(WideCfg<false>::kBlock == WideCfg<true>::kBlock && WideCfg<false>::kTop == WideCfg<true>::kTop &&
+                  WideCfg<false>::kWaves == WideCfg<true>::kWaves, "the fused launch needs one block shape");
+template <bool COUNT>
+__global__ __launch_bounds__(WideCfg<false>::kBlock) __attribute__((amdgpu_waves_per_eu(WideCfg<false>::kWaves, WideCfg<false>::kWaves)))
+void k_trace_wide_both(DevScene s, const float4* __restrict__ raysC, const int* __restrict__ indexC, QueueView qC,
+                       unsigned* __restrict__ cursorC, float4* __restrict__ hits, unsigned long long* __restrict__ countersC,
+                       unsigned* __restrict__ slowCountC, int* __restrict__ slowListC,
+                       const float4* __restrict__ raysO, const int* __restrict__ targetO, QueueView qO,
+                       unsigned* __restrict__ cursorO, unsigned char* __restrict__ occ, unsigned long long* __restrict__ countersO,
+                       unsigned* __restrict__ slowCountO, int* __restrict__ slowListO, int shadowFirst) {
+    PT_WIDE_LDS_DECL(WideCfg<false>::kBlock, WideCfg<false>::kTop);
+    const int nTop = s.nWideTop < WideCfg<false>::kTop ? s.nWideTop : WideCfg<false>::kTop;
+    wide_load_top(s, ldsTop, nTop, WideCfg<false>::kBlock);
+    wide_prefix(qC, ldsPrefix[0], 0, &ldsPool[0], ldsPoolCtl[0], WideCfg<false>::kBlock / 64);
+    wide_prefix(qO, ldsPrefix[1], 1, &ldsPool[1], ldsPoolCtl[1], WideCfg<false>::kBlock / 64);
+    __syncthreads();
+    if (shadowFirst)
+        wide_body<true, COUNT>(s, raysO, nullptr, targetO, qO, cursorO, nullptr, occ, countersO, slowCountO, slowListO,
+                               WideLds{ldsTop, ldsStack, ldsPrefix[1], ldsPair, ldsKey, ldsOut, &ldsPool[1], ldsPoolCtl[1]});
+    wide_body<false, COUNT>(s, raysC, indexC, nullptr, qC, cursorC, hits, nullptr, countersC, slowCountC, slowListC,
+                            WideLds{ldsTop, ldsStack, ldsPrefix[0], ldsPair, ldsKey, ldsOut, &ldsPool[0], ldsPoolCtl[0]});
+    if (!shadowFirst)
+        wide_body<true, COUNT>(s, raysO, nullptr, targetO, qO, cursorO, nullptr, occ, countersO, slowCountO, slowListO,
+                               WideLds{ldsTop, ldsStack, ldsPrefix[1], ldsPair, ldsKey, ldsOut, &ldsPool[1], ldsPoolCtl[1]});
+}
+#endif
 
 template <bool ANYHIT>
 static inline unsigned wide_grid(size_t nMax) {
@@ -766,4 +1119,31 @@ void launch_trace_wide_occluded(hipStream_t st, const DevScene& s, const float4*
                            nullptr, occ, counters, slowCount, slowList);
 }
 
+#if PT_WIDE_K == 8
+void launch_trace_wide_both(hipStream_t st, const DevScene& s, const float4* raysC, const int* indexC, QueueView qC, unsigned* cursorC,
+                            float4* hits, unsigned long long* countersC, unsigned* slowCountC, int* slowListC, const float4* raysO,
+                            const int* targetO, QueueView qO, unsigned* cursorO, unsigned char* occ, unsigned long long* countersO,
+                            unsigned* slowCountO, int* slowListO, int shadowFirst) {
+    const unsigned g = wide_grid<false>((size_t)qC.space + qO.space);
+    if (countersC)
+        hipLaunchKernelGGL((k_trace_wide_both<true>), dim3(g), dim3(WideCfg<false>::kBlock), 0, st, s, raysC, indexC, qC, cursorC, hits,
+                           countersC, slowCountC, slowListC, raysO, targetO, qO, cursorO, occ, countersO, slowCountO, slowListO, shadowFirst);
+    else
+        hipLaunchKernelGGL((k_trace_wide_both<false>), dim3(g), dim3(WideCfg<false>::kBlock), 0, st, s, raysC, indexC, qC, cursorC, hits,
+                           countersC, slowCountC, slowListC, raysO, targetO, qO, cursorO, occ, countersO, slowCountO, slowListO, shadowFirst);
+}
+#endif
+
 }  // namespace ptd
+
+#if PT_DIAG_TAIL
+// diagnostic builds only; not part of include/mipt.h
+extern "C" int mipt_debug_tail(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_tailDiag), 4 * 4096 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ptd::g_tailDiag)) != hipSuccess || hipMemset(p, 0, 4 * 4096 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
