@@ -61,6 +61,7 @@ int resolve_scratch(int device) {
     void* p = nullptr;
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     if (!p) { pt::set_error("hipGetSymbolAddress(scratch) returned null"); return MIPT_ERR_DEVICE; }
+    HIP_TRY(hipMemset((unsigned char*)p + kNoAllocHeaderBytes, 0xff, sizeof(int) * kNoAllocMaxRays));  // the list rests at -1 (ensure_slow)
     g_scratchPtr[device] = p;
     return MIPT_OK;
 }
@@ -779,9 +780,16 @@ void count_launch(mipt_ctx* c, int cls) {
 // Scenes that qualify (DevScene::nWide) go through the wide kernel first; it hands back the rays it may not take
 // (direction components that are zero, denormal, non-finite ...) in c->slow, and the literal walk traces those.
 // c->slow: [0] count, [1] cursor of the second launch, [2..] queue slots.
+// c->slow / c->slowOcc: [0] count, [1] cursor of the list-mode launch, [2] blocks of the wide launch that are done, [3] -,
+// [kSlowHeader..] queue slots.  The list RESTS at -1 everywhere: whoever takes an entry puts -1 back (k_trace_wide's
+// draining wavefronts tell "not written yet / taken" from "to do" by that), so a fresh buffer is filled once.
+constexpr size_t kSlowHeader = 4;
 int ensure_slow(mipt_ctx* c, DevBuf& buf, size_t capacity, hipStream_t st) {
-    int rc = buf.ensure((capacity + 2) * sizeof(int));
-    if (rc == MIPT_OK) (void)hipMemsetAsync(buf.p, 0, 8, st);
+    const void* before = buf.p;
+    int rc = buf.ensure((capacity + kSlowHeader) * sizeof(int));
+    if (rc != MIPT_OK) return rc;
+    if (buf.p != before && hipMemsetAsync(buf.p, 0xff, buf.bytes, st) != hipSuccess) return fail(MIPT_ERR_DEVICE, "hipMemsetAsync(hand-back list) failed");
+    (void)hipMemsetAsync(buf.p, 0, kSlowHeader * sizeof(int), st);
     return rc;
 }
 void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, unsigned* cursor, float4* hits) {
@@ -796,9 +804,9 @@ void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView 
         launch_trace_bittrail_closest(c->stream, c->ds, rays, index, q, hits, cnt);
     } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slow, q.space, c->stream) == MIPT_OK) {
         unsigned* sl = (unsigned*)c->slow.p;
-        launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, sl, (int*)(sl + 2));
-        launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, (const int*)(sl + 2), sl);  // short list: a wavefront per ray
-        launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, sl + 1, hits, cnt, (const int*)(sl + 2), sl);  // long list: a lane per ray
+        launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, sl, (int*)(sl + kSlowHeader));
+        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, (int*)(sl + kSlowHeader), sl);  // short list: a wavefront per ray (else k_trace_wide's own wavefronts have done it)
+        launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, sl + 1, hits, cnt, (int*)(sl + kSlowHeader), sl);  // long list: a lane per ray
     } else {
         launch_trace_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt);
     }
@@ -819,9 +827,9 @@ void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueVie
         launch_trace_bittrail_occluded(st, c->ds, rays, target, q, occ, cnt);
     } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slowOcc, q.space, st) == MIPT_OK) {
         unsigned* sl = (unsigned*)c->slowOcc.p;
-        launch_trace_wide_occluded(st, c->ds, rays, target, q, cursor, occ, cnt, sl, (int*)(sl + 2));
-        launch_trace_slow_occluded(st, c->ds, rays, target, occ, cnt, (const int*)(sl + 2), sl);
-        launch_trace_occluded(st, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, sl + 1, occ, cnt, (const int*)(sl + 2), sl);
+        launch_trace_wide_occluded(st, c->ds, rays, target, q, cursor, occ, cnt, sl, (int*)(sl + kSlowHeader));
+        if (!c->ds.drain) launch_trace_slow_occluded(st, c->ds, rays, target, occ, cnt, (int*)(sl + kSlowHeader), sl);
+        launch_trace_occluded(st, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, sl + 1, occ, cnt, (int*)(sl + kSlowHeader), sl);
     } else {
         launch_trace_occluded(st, c->ds, rays, target, q, cursor, occ, cnt);
     }
@@ -840,12 +848,12 @@ bool trace_both(mipt_ctx* c, const float4* raysC, const int* indexC, QueueView q
     unsigned long long* cntO = c->counting ? c->dTotals + 4 : nullptr;
     unsigned* sc = (unsigned*)c->slow.p;
     unsigned* so = (unsigned*)c->slowOcc.p;
-    launch_trace_wide_both(c->stream, c->ds, raysC, indexC, qC, cursorC, hits, cntC, sc, (int*)(sc + 2), raysO, targetO, qO, cursorO, occ,
-                           cntO, so, (int*)(so + 2), c->shadowFirst ? 1 : 0);
-    launch_trace_slow_closest(c->stream, c->ds, raysC, indexC, hits, cntC, (const int*)(sc + 2), sc);
-    launch_trace_closest(c->stream, c->ds, raysC, indexC, QueueView{nullptr, 0u, qC.space}, sc + 1, hits, cntC, (const int*)(sc + 2), sc);
-    launch_trace_slow_occluded(c->stream, c->ds, raysO, targetO, occ, cntO, (const int*)(so + 2), so);
-    launch_trace_occluded(c->stream, c->ds, raysO, targetO, QueueView{nullptr, 0u, qO.space}, so + 1, occ, cntO, (const int*)(so + 2), so);
+    launch_trace_wide_both(c->stream, c->ds, raysC, indexC, qC, cursorC, hits, cntC, sc, (int*)(sc + kSlowHeader), raysO, targetO, qO, cursorO, occ,
+                           cntO, so, (int*)(so + kSlowHeader), c->shadowFirst ? 1 : 0);
+    if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, raysC, indexC, hits, cntC, (int*)(sc + kSlowHeader), sc);
+    launch_trace_closest(c->stream, c->ds, raysC, indexC, QueueView{nullptr, 0u, qC.space}, sc + 1, hits, cntC, (int*)(sc + kSlowHeader), sc);
+    if (!c->ds.drain) launch_trace_slow_occluded(c->stream, c->ds, raysO, targetO, occ, cntO, (int*)(so + kSlowHeader), so);
+    launch_trace_occluded(c->stream, c->ds, raysO, targetO, QueueView{nullptr, 0u, qO.space}, so + 1, occ, cntO, (int*)(so + kSlowHeader), so);
     return true;
 #else
     return false;
@@ -1210,6 +1218,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.nNodes = s->nNodes; c->ds.nLeafTris = s->nLeafTris; c->ds.nTris = s->nTris; c->ds.nMaterials = s->nMaterials;
     c->ds.envW = s->envW; c->ds.envH = s->envH; c->ds.nLights = s->nLights;
     c->ds.planesTame = s->planesTame ? 1 : 0;
+    c->ds.drain = 1;
+    if (const char* dv = getenv("MIPT_DRAIN")) c->ds.drain = std::string(dv) != "0" ? 1 : 0;  // A/B runs
     if (const char* hb = getenv("MIPT_HAND_BACK_ALL")) c->ds.handBackAll = std::string(hb) == "1" ? 1 : 0;  // tests: every ray through k_trace_slow / list-mode k_trace
     c->ds.nTopNodes = s->nTopNodes;
     c->ds.wnodes = (const float4*)(base + oWide);
@@ -1456,7 +1466,7 @@ int mipt_trace_device_noalloc(mipt_ctx* c, const void* rays_dev, size_t n, void*
         launch_trace_bittrail_closest(c->stream, c->ds, rays, nullptr, q, hits, cnt);
     } else if (c->ds.nWide > 0 && c->useWide) {
         launch_trace_wide_closest(c->stream, c->ds, rays, nullptr, q, cursor, hits, cnt, head, list);
-        launch_trace_slow_closest(c->stream, c->ds, rays, nullptr, hits, cnt, list, head);
+        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, nullptr, hits, cnt, list, head);
         launch_trace_closest(c->stream, c->ds, rays, nullptr, QueueView{nullptr, 0u, q.space}, head + 1, hits, cnt, list, head);
     } else {
         launch_trace_closest(c->stream, c->ds, rays, nullptr, q, cursor, hits, cnt);
@@ -1624,7 +1634,7 @@ static int ensure_path_buffers(mipt_ctx* c, size_t cap, size_t nPix) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = c->pathMem.ensure(o);
     if (rc != MIPT_OK) { c->pb.capacity = 0; c->pbPixels = 0; return rc; }
-    if ((rc = c->slow.ensure((space + 2) * sizeof(int))) != MIPT_OK || (rc = c->slowOcc.ensure((space * nl + 2) * sizeof(int))) != MIPT_OK) {
+    if ((rc = ensure_slow(c, c->slow, space, c->stream)) != MIPT_OK || (rc = ensure_slow(c, c->slowOcc, space * nl, c->stream)) != MIPT_OK) {
         c->pb.capacity = 0; c->pbPixels = 0; return rc;
     }
     c->pbPixels = nPix;

@@ -73,6 +73,8 @@ struct DevScene {
     float wideInvScale;     // the fp16 planes of the wide nodes are the scene's planes times a power of two S (so that any
                             // tame scene fits fp16's range at full relative precision); this is 1 / S
     int nTopNodes;   // nodes [0, nTopNodes) are the top of the tree, numbered first so that k_trace can hold them in LDS
+    int drain;       // k_trace_wide's own wavefronts trace the rays the launch hands back (kernels_trace_wide.hip, "Draining the
+                     // hand-back list"); 0 (MIPT_DRAIN=0 when the context is made): k_trace_slow does, in a launch of its own
     int handBackAll; // test switch (MIPT_HAND_BACK_ALL=1 when the context is made): k_trace_wide hands EVERY ray to the exact walk kernels
     int planesTame;  // every box plane is 0 or has magnitude in [2^-61, 2^40] and min <= max: the exact reciprocal slab division may be used (traverse.hpp)
 };

@@ -80,10 +80,10 @@ struct FrameParams {
 // cursor: one zeroed word per launch (the work counter the persistent wavefronts pull ray chunks from)
 // literal threaded walk (kernels_trace.hip).  remap != nullptr: trace only the queue slots remap[0 .. *remapCount)
 void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
-                          unsigned* cursor, float4* hits, unsigned long long* counters, const int* remap = nullptr,
+                          unsigned* cursor, float4* hits, unsigned long long* counters, int* remap = nullptr,
                           const unsigned* remapCount = nullptr);
 void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
-                           unsigned* cursor, unsigned char* occ, unsigned long long* counters, const int* remap = nullptr,
+                           unsigned* cursor, unsigned char* occ, unsigned long long* counters, int* remap = nullptr,
                            const unsigned* remapCount = nullptr);
 // order-free traversal over the 4-wide tree (kernels_trace_wide.hip) for the rays that qualify; the queue slots of
 // the others are appended to slowList (count in *slowCount) for a literal walk afterwards
@@ -99,9 +99,9 @@ void launch_trace_wide_both(hipStream_t st, const DevScene& s, const float4* ray
                             const int* targetO, QueueView qO, unsigned* cursorO, unsigned char* occ, unsigned long long* countersO,
                             unsigned* slowCountO, int* slowListO, int shadowFirst);
 void launch_trace_slow_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, float4* hits,
-                               unsigned long long* counters, const int* list, const unsigned* listCount);
+                               unsigned long long* counters, int* list, const unsigned* listCount);
 void launch_trace_slow_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, unsigned char* occ,
-                                unsigned long long* counters, const int* list, const unsigned* listCount);
+                                unsigned long long* counters, int* list, const unsigned* listCount);
 // StacklessBVH2::intersect, literal (kernels_trace_bittrail.hip); needs s.btOk
 void launch_trace_bittrail_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
                                    float4* hits, unsigned long long* counters);

@@ -74,7 +74,6 @@ constexpr int kPendAnyHit = PT_TUNE_PEND_ANYHIT;  // any-hit rays end at their f
 #define PT_TUNE_WAVES_PER_EU 8
 #endif
 #define PT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(PT_TUNE_WAVES_PER_EU, PT_TUNE_WAVES_PER_EU)))
-constexpr unsigned kSlowMaxRays = 4096;  // lists up to this long go to k_trace_slow, longer ones to k_trace
 constexpr int kSlowGrid = 256;           // wavefronts of k_trace_slow (an idle launch costs a few microseconds per 256)
 constexpr int kSlowStack = 8192;         // node stack of one k_trace_slow wavefront (32 KB of LDS)
 
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                                                   QueueView q, unsigned* __restrict__ cursor,
                                                   float4* __restrict__ hits, unsigned char* __restrict__ occ,
                                                   unsigned long long* __restrict__ counters,
-                                                  const int* __restrict__ remap, const unsigned* __restrict__ remapCount) {
+                                                  int* __restrict__ remap, const unsigned* __restrict__ remapCount) {
     // remap != nullptr: the queue is the list remap[0 .. *remapCount) of queue slots (the rays k_trace_wide handed
     // back, kernels_trace_wide.hip); most launches find it empty
     // (short lists belong to k_trace_slow below: a wavefront per ray instead of a lane per ray)
@@ -196,6 +195,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                     unsigned slot = j;
                     if (remap) {
                         slot = (unsigned)remap[j];  // -1: a k_trace_wide wavefront has traced this one already
+                        remap[j] = -1;              // the list's resting state
                     } else if (q.counts) {  // dense index -> shard: j < total = prefix[kShards] ends the loop
                         unsigned sh = chunkShard;
                         while (j >= prefix[sh + 1]) ++sh;
@@ -433,7 +433,7 @@ template <bool ANYHIT, bool COUNT>
 __global__ __launch_bounds__(64) void k_trace_slow(DevScene s, const float4* __restrict__ rays, const int* __restrict__ index,
                                                    const int* __restrict__ target, float4* __restrict__ hits,
                                                    unsigned char* __restrict__ occ, unsigned long long* __restrict__ counters,
-                                                   const int* __restrict__ list, const unsigned* __restrict__ listCount) {
+                                                   int* __restrict__ list, const unsigned* __restrict__ listCount) {
     __shared__ int stack[kSlowStack];
     const unsigned n = *listCount;
     if (n > kSlowMaxRays || !s.slowOk) return;  // k_trace takes long lists, and every list of a tree too deep for this stack
@@ -455,6 +455,7 @@ __global__ __launch_bounds__(64) void k_trace_slow(DevScene s, const float4* __r
             } else {
                 hits[raySlot] = make_float4(i2f(bestTri), bestT, bestB, bestG);
             }
+            list[r] = -1;  // the list's resting state
         }
         wave_lds_sync();
     }
@@ -486,7 +487,7 @@ static inline unsigned trace_grid(size_t nMax) {
     return (unsigned)g;
 }
 void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
-                          unsigned* cursor, float4* hits, unsigned long long* counters, const int* remap,
+                          unsigned* cursor, float4* hits, unsigned long long* counters, int* remap,
                           const unsigned* remapCount) {
     const unsigned g = trace_grid(q.space);
     if (counters)
@@ -497,7 +498,7 @@ void launch_trace_closest(hipStream_t st, const DevScene& s, const float4* rays,
                            nullptr, counters, remap, remapCount);
 }
 void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
-                           unsigned* cursor, unsigned char* occ, unsigned long long* counters, const int* remap,
+                           unsigned* cursor, unsigned char* occ, unsigned long long* counters, int* remap,
                            const unsigned* remapCount) {
     const unsigned g = trace_grid(q.space);
     if (counters)
@@ -509,14 +510,14 @@ void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays
 }
 // the rays list[0 .. *listCount) (queue slots), a wavefront each; a no-op for lists longer than kSlowMaxRays
 void launch_trace_slow_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, float4* hits,
-                               unsigned long long* counters, const int* list, const unsigned* listCount) {
+                               unsigned long long* counters, int* list, const unsigned* listCount) {
     if (counters)
         hipLaunchKernelGGL((k_trace_slow<false, true>), dim3(kSlowGrid), dim3(64), 0, st, s, rays, index, nullptr, hits, nullptr, counters, list, listCount);
     else
         hipLaunchKernelGGL((k_trace_slow<false, false>), dim3(kSlowGrid), dim3(64), 0, st, s, rays, index, nullptr, hits, nullptr, counters, list, listCount);
 }
 void launch_trace_slow_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, unsigned char* occ,
-                                unsigned long long* counters, const int* list, const unsigned* listCount) {
+                                unsigned long long* counters, int* list, const unsigned* listCount) {
     if (counters)
         hipLaunchKernelGGL((k_trace_slow<true, true>), dim3(kSlowGrid), dim3(64), 0, st, s, rays, nullptr, target, nullptr, occ, counters, list, listCount);
     else

@@ -28,6 +28,7 @@
 // is traced by k_trace_slow (a wavefront per ray) or, when it is long, by the literal k_trace (kernels_trace.hip).
 #include "kernels.hpp"
 #include "shading.hpp"
+#include "slow_walk.hpp"
 
 namespace ptd {
 
@@ -266,6 +267,9 @@ constexpr unsigned kPendMask = 15u;
 #ifndef PT_WIDE_POOL
 #define PT_WIDE_POOL 1  // rays reach the wavefronts through a pool per BLOCK in LDS (below: "The block's pool"); 0: one chunk per wavefront from the global cursor
 #endif
+#ifndef PT_WIDE_DRAIN
+#define PT_WIDE_DRAIN 1  // the wavefronts that finish first trace the rays the launch has handed back ("Draining the hand-back list" in the body)
+#endif
 #ifndef PT_TUNE_WIDE_POOL_MIN
 #define PT_TUNE_WIDE_POOL_MIN 256u    // smallest / largest chunk a block asks the launch's cursor for
 #endif
@@ -301,7 +305,8 @@ struct WideLds {
     unsigned long long* key;      // per owner lane: min over its helpers of t << 32 | index
     unsigned* out;                // per owner lane: helpers still out | failed << 31
     unsigned long long* pool;     // the block's pool of rays: next dense index << 32 | end of the chunk
-    unsigned* poolCtl;            // [0] lock of the one wavefront that refills the pool, [1] the launch's queue is empty
+    unsigned* poolCtl;            // [0] lock of the one wavefront that refills the pool, [1] the launch's queue is empty,
+                                  // [2] wavefronts of this block that have left the main loop
 };
 #define PT_WIDE_LDS_DECL(KBLK, KTOP)                                                                       \
     __shared__ float4 ldsTop[kWideNodeF4 * (KTOP)];                                                        \
@@ -311,7 +316,7 @@ struct WideLds {
     __shared__ unsigned long long ldsKey[(PT_WIDE_SHARE && PT_WIDE_K == 8) ? (KBLK) : 1];                  \
     __shared__ unsigned ldsOut[(PT_WIDE_SHARE && PT_WIDE_K == 8) ? (KBLK) : 1];                            \
     __shared__ unsigned long long ldsPool[2];                                                              \
-    __shared__ unsigned ldsPoolCtl[2][2]
+    __shared__ unsigned ldsPoolCtl[2][4]
 // the top of the tree into LDS (packed there, kWideNodeStrideF4 apart in the arena)
 __device__ __forceinline__ void wide_load_top(const DevScene& s, float4* top, int nTop, int kBlk) {
     for (int i = threadIdx.x; i < kWideNodeF4 * nTop; i += kBlk)
@@ -347,6 +352,7 @@ __device__ __forceinline__ void wide_prefix(const QueueView& q, unsigned* prefix
         *pool = ((unsigned long long)base << 32) | (unsigned long long)(base + len);
         poolCtl[0] = 0u;
         poolCtl[1] = (unsigned long long)gridDim.x * C0 >= (unsigned long long)total ? 1u : 0u;  // nothing behind the static chunks
+        poolCtl[2] = 0u;
     }
 }
 
@@ -474,6 +480,8 @@ __device__ __forceinline__ void wide_body(
     unsigned diagGifts = 0;
 #endif
 
+// an entry of the hand-back list: written through to the memory side, where the other XCDs' wavefronts will look for it
+#define PT_LIST_PUT(I, SLOT) __hip_atomic_store(&slowList[I], (int)(SLOT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PT_FINISH()                                                                        \
     do {                                                                                   \
         if (ANYHIT) {                                                                      \
@@ -729,7 +737,7 @@ __device__ __forceinline__ void wide_body(
                     unsigned at = 0;
                     if (lane == 0) at = atomicAdd(slowCount, (unsigned)__popcll(mSlow));
                     at = __shfl(at, 0);
-                    if (slow) slowList[at + (unsigned)__popcll(mSlow & ((1ull << lane) - 1ull))] = (int)queueSlot;
+                    if (slow) PT_LIST_PUT(at + (unsigned)__popcll(mSlow & ((1ull << lane) - 1ull)), queueSlot);
                 }
             }
         }
@@ -967,7 +975,7 @@ __device__ __forceinline__ void wide_body(
                     // the filtering since that candidate may have dropped the true winner: trace this ray again, exactly
                     if (!SHARE || role == -1) {
                         unsigned at = atomicAdd(slowCount, 1u);
-                        slowList[at] = (int)queueSlot;
+                        PT_LIST_PUT(at, queueSlot);
                         PT_RESET_LANE();
                     } else if (role >= 0) {  // a helper: mark the owner's ray, count off, fall idle
                         __hip_atomic_fetch_or(&shareOut[waveBase + (unsigned)role], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -994,7 +1002,7 @@ __device__ __forceinline__ void wide_body(
                 if ((out & 0x7fffffffu) == 0u) {  // every helper has reported
                     if (out != 0u) {  // some verdict failed: the exact walk traces this ray again
                         unsigned at = atomicAdd(slowCount, 1u);
-                        slowList[at] = (int)queueSlot;
+                        PT_LIST_PUT(at, queueSlot);
                         PT_RESET_LANE();
                     } else {
                         const unsigned long long theirs = __hip_atomic_load(&shareKey[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1018,8 +1026,72 @@ __device__ __forceinline__ void wide_body(
         }
     }
 #undef PT_FINISH
+#undef PT_LIST_PUT
 #undef PT_RESET_LANE
 #undef PT_WALK_OVER
+#if PT_WIDE_DRAIN
+    // Draining the hand-back list (round 3).  The few rays a launch hands back (slowList: a zero direction component, a
+    // failed verdict) used to wait for two more launches (k_trace_slow, list-mode k_trace), 20 to 35 us per traversal
+    // on the frame's critical path.  Now every wavefront that leaves the loop above looks at the list as it stands and
+    // traces what it can take -- an entry is taken by exchanging it with -1, the list's resting state -- with the whole
+    // wavefront per ray (slow_walk.hpp) on the LDS its lanes' stacks occupy; it then counts itself off, and the last
+    // wavefront of the last block, which by then can see every entry, looks once more.  Nobody waits for anybody, so
+    // blocks that are not resident yet cannot be waited for.  Lists longer than kSlowMaxRays and trees too deep for the
+    // stack stay with list-mode k_trace (a lane per ray), which skips what has been taken.
+    // (Visibility without fences: an agent-scope fence writes the whole L2 of the wavefront's XCD back -- 4,096 of them cost
+    // 160 us per launch when tried.  The list is therefore written, read and taken with agent-scope ATOMICS only, which
+    // act at the memory side and need no cache maintenance, and a wavefront waits for its own outstanding memory
+    // operations (s_waitcnt) before it counts itself off, so that its entries are there when the count says so.)
+    if (s.drain && s.slowOk) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);  // this wavefront's own entries are out before it is counted off
+        int* const wstack = (int*)stackLds + waveBase;
+        for (int pass = 0; pass < 2; pass++) {
+            unsigned n = 0;
+            if (lane == 0) n = __hip_atomic_load(slowCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n = (unsigned)__builtin_amdgcn_readfirstlane((int)n);
+            if (n != 0u && n <= kSlowMaxRays) {
+                for (unsigned base = 0; base < n; base += 64u) {
+                    int e = -1;
+                    if (base + (unsigned)lane < n) e = __hip_atomic_load(&slowList[base + (unsigned)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long m = __ballot(e >= 0);
+                    while (m != 0ull) {
+                        const int j = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        int got = -1;
+                        if (lane == 0) got = atomicExch(&slowList[base + (unsigned)j], -1);
+                        got = __builtin_amdgcn_readfirstlane(got);
+                        if (got < 0) continue;  // another wavefront was faster
+                        const unsigned slot = (unsigned)got;
+                        const unsigned rsl = index ? (unsigned)index[slot] : slot;
+                        const size_t rs = ANYHIT ? (size_t)slot : (size_t)rsl;
+                        const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
+                        int bTri, bSeq;
+                        float bT, bB, bG;
+                        slow_walk_wave<ANYHIT, COUNT, kBlk>(s, vec3{r0.x, r0.y, r0.z}, vec3{r1.x, r1.y, r1.z}, r0.w, r1.w, wstack,
+                                                            64 * kWideMaxDepth, lane, bTri, bSeq, bT, bB, bG, nv, nt);
+                        if (lane == 0) {
+                            if (ANYHIT) {
+                                if (bTri >= 0) occ[target ? (unsigned)target[slot] : slot] = 1;
+                            } else {
+                                hits[rsl] = make_float4(i2f(bTri), bT, bB, bG);
+                            }
+                        }
+                        wave_lds_sync();
+                    }
+                }
+            }
+            if (pass == 1) break;
+            int last = 0;
+            if (lane == 0) {
+                if (__hip_atomic_fetch_add(&poolCtl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(kBlk / 64) - 1u)
+                    last = atomicAdd(&slowCount[2], 1u) == gridDim.x - 1u ? 1 : 0;
+            }
+            if (!__builtin_amdgcn_readfirstlane(last)) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+#endif
 #if PT_DIAG_TAIL
     if (lane == 0 && !ANYHIT && gw < 4096u) {
         g_tailDiag[4 * gw] = diagStart;

@@ -15,6 +15,7 @@
 
 namespace ptd {
 
+constexpr unsigned kSlowMaxRays = 4096;  // lists up to this long are traced a wavefront per ray, longer ones by list-mode k_trace, a lane per ray
 constexpr int kSlowReserve = 256;  // stack entries kept free for one-node-at-a-time steps
 
 // order within one wavefront: its LDS operations complete in program order, the compiler must keep them there

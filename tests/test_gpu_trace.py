@@ -351,8 +351,8 @@ def test_rays_through_vertices_and_the_exact_walk_kernels_on_ordinary_rays(B, ob
     reference keeps the first in depth-first order, cs488.h:1674), and leaf boxes the exact predicate rejects although
     one of their triangles accepts the ray -- the cases the order-free traversal's deferred admission must get right
     (an unverified best whose leaf box fails sends the ray to the exact walk kernels).  Second half: with
-    MIPT_HAND_BACK_ALL=1 every ray takes those kernels (k_trace_slow for short lists, list-mode k_trace for long
-    ones), which since deferred admission also see rays with ordinary directions"""
+    MIPT_HAND_BACK_ALL=1 every ray takes the exact walk (a wavefront per ray for short lists, list-mode k_trace for long
+    ones), which since deferred admission also sees rays with ordinary directions"""
     arrays = sf.sponza_standin(1) if name == "sponza-standin-trace" else sf.load_scene_arrays(name)
     scene = sf.product_scene_from_mesh_arrays(*arrays)
     orc = sf.oracle_scene_from_mesh_arrays(*arrays)
@@ -366,14 +366,20 @@ def test_rays_through_vertices_and_the_exact_walk_kernels_on_ordinary_rays(B, ob
         ref = orc.intersect(o, d)
         oref = orc.occluded(o, d, 1e-4, 2.0)
         assert (ref[0] >= 0).mean() > 0.5
-        for hand_back in ("0", "1"):
+        # MIPT_DRAIN=1 (the default): lists of up to 4,096 rays are traced by k_trace_wide's own wavefronts as they finish
+        # (round 3), =0: by k_trace_slow in a launch of its own; twice per context, since the list must be back at rest
+        # (-1 everywhere) after every call
+        for hand_back, drain in (("0", "1"), ("1", "1"), ("1", "0")):
             monkeypatch.setenv("MIPT_HAND_BACK_ALL", hand_back)
+            monkeypatch.setenv("MIPT_DRAIN", drain)
             ctx = B.Context(scene, device=0)
-            got = ctx.trace(o, d)
-            assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and \
-                np.array_equal(bits(got[2]), bits(ref[2])), (name, n, hand_back)
-            assert np.array_equal(ctx.occluded(o, d, 1e-4, 2.0), oref), (name, n, hand_back)
+            for rep in range(2):
+                got = ctx.trace(o, d)
+                assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and \
+                    np.array_equal(bits(got[2]), bits(ref[2])), (name, n, hand_back, drain, rep)
+                assert np.array_equal(ctx.occluded(o, d, 1e-4, 2.0), oref), (name, n, hand_back, drain, rep)
         monkeypatch.delenv("MIPT_HAND_BACK_ALL")
+        monkeypatch.delenv("MIPT_DRAIN")
 
 
 @pytest.mark.parametrize("name", ["teapot-glass", "testObj", "sponza"])
