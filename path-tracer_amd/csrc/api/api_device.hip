@@ -695,6 +695,7 @@ struct mipt_ctx {
     DevBuf sRays, sHits, sOut, sAux, sAux2;
     DevBuf slow;           // rays the wide kernel handed back (trace_closest)
     DevBuf slowOcc;        // ... and those of trace_occluded, which may run beside a closest-hit launch on the side stream
+    int slowParity = 0, slowOccParity = 0;  // which of a list's two headers the next launch uses (ensure_slow)
     // Path mode overlaps occluded(it) with closest(it+1): once shade(it) has run the two are independent, and on a
     // second stream the blocks of the later kernel move onto CUs as the earlier one's drain, which fills the
     // 0.1-0.2 ms tail of every traversal launch (MIPT_OVERLAP=0 in the environment turns it off for A/B runs).
@@ -780,17 +781,33 @@ void count_launch(mipt_ctx* c, int cls) {
 // Scenes that qualify (DevScene::nWide) go through the wide kernel first; it hands back the rays it may not take
 // (direction components that are zero, denormal, non-finite ...) in c->slow, and the literal walk traces those.
 // c->slow: [0] count, [1] cursor of the second launch, [2..] queue slots.
-// c->slow / c->slowOcc: [0] count, [1] cursor of the list-mode launch, [2] blocks of the wide launch that are done, [3] -,
-// [kSlowHeader..] queue slots.  The list RESTS at -1 everywhere: whoever takes an entry puts -1 back (k_trace_wide's
-// draining wavefronts tell "not written yet / taken" from "to do" by that), so a fresh buffer is filled once.
-constexpr size_t kSlowHeader = 4;
-int ensure_slow(mipt_ctx* c, DevBuf& buf, size_t capacity, hipStream_t st) {
+// c->slow / c->slowOcc: TWO headers of four words used in turn ([0] count, [1] cursor of the list-mode launch, [2] blocks of
+// the wide launch that are done, [3] -), then the queue slots from word kSlowHeader on.  A wide launch zeroes the OTHER
+// header for the launch after it, so nothing is memset between launches.  The list RESTS at -1 everywhere: whoever
+// takes an entry puts -1 back (k_trace_wide's draining wavefronts tell "not written yet / taken" from "to do" by that),
+// so a fresh buffer is filled once.
+constexpr size_t kSlowHeader = 8;
+struct SlowView {
+    unsigned* head;  // this launch's header
+    unsigned* next;  // the one it zeroes
+    int* list;
+};
+// use: a launch follows (the headers change places); false: only make sure the buffer is large enough
+int ensure_slow(mipt_ctx* c, DevBuf& buf, int& parity, size_t capacity, hipStream_t st, SlowView& v, bool use = true) {
     const void* before = buf.p;
     int rc = buf.ensure((capacity + kSlowHeader) * sizeof(int));
     if (rc != MIPT_OK) return rc;
-    if (buf.p != before && hipMemsetAsync(buf.p, 0xff, buf.bytes, st) != hipSuccess) return fail(MIPT_ERR_DEVICE, "hipMemsetAsync(hand-back list) failed");
-    (void)hipMemsetAsync(buf.p, 0, kSlowHeader * sizeof(int), st);
-    return rc;
+    if (buf.p != before) {
+        if (hipMemsetAsync(buf.p, 0xff, buf.bytes, st) != hipSuccess || hipMemsetAsync(buf.p, 0, kSlowHeader * sizeof(int), st) != hipSuccess)
+            return fail(MIPT_ERR_DEVICE, "hipMemsetAsync(hand-back list) failed");
+        parity = 0;
+    }
+    unsigned* base = (unsigned*)buf.p;
+    v.head = base + 4 * parity;
+    v.next = base + 4 * (parity ^ 1);
+    v.list = (int*)(base + kSlowHeader);
+    if (use) parity ^= 1;
+    return MIPT_OK;
 }
 void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, unsigned* cursor, float4* hits) {
     if (!cursor) {
@@ -802,11 +819,10 @@ void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView 
     unsigned long long* cnt = c->counting ? c->dTotals + 2 : nullptr;
     if (c->useBitTrail) {
         launch_trace_bittrail_closest(c->stream, c->ds, rays, index, q, hits, cnt);
-    } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slow, q.space, c->stream) == MIPT_OK) {
-        unsigned* sl = (unsigned*)c->slow.p;
-        launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, sl, (int*)(sl + kSlowHeader));
-        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, (int*)(sl + kSlowHeader), sl);  // short list: a wavefront per ray (else k_trace_wide's own wavefronts have done it)
-        launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, sl + 1, hits, cnt, (int*)(sl + kSlowHeader), sl);  // long list: a lane per ray
+    } else if (SlowView v{}; c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slow, c->slowParity, q.space, c->stream, v) == MIPT_OK) {
+        launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, v.head, v.list, v.next);
+        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, v.list, v.head);  // short list: a wavefront per ray (else k_trace_wide's own wavefronts have done it)
+        launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, v.head + 1, hits, cnt, v.list, v.head);  // long list: a lane per ray
     } else {
         launch_trace_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt);
     }
@@ -825,11 +841,10 @@ void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueVie
     unsigned long long* cnt = c->counting ? c->dTotals + 4 : nullptr;
     if (c->useBitTrail) {
         launch_trace_bittrail_occluded(st, c->ds, rays, target, q, occ, cnt);
-    } else if (c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slowOcc, q.space, st) == MIPT_OK) {
-        unsigned* sl = (unsigned*)c->slowOcc.p;
-        launch_trace_wide_occluded(st, c->ds, rays, target, q, cursor, occ, cnt, sl, (int*)(sl + kSlowHeader));
-        if (!c->ds.drain) launch_trace_slow_occluded(st, c->ds, rays, target, occ, cnt, (int*)(sl + kSlowHeader), sl);
-        launch_trace_occluded(st, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, sl + 1, occ, cnt, (int*)(sl + kSlowHeader), sl);
+    } else if (SlowView v{}; c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slowOcc, c->slowOccParity, q.space, st, v) == MIPT_OK) {
+        launch_trace_wide_occluded(st, c->ds, rays, target, q, cursor, occ, cnt, v.head, v.list, v.next);
+        if (!c->ds.drain) launch_trace_slow_occluded(st, c->ds, rays, target, occ, cnt, v.list, v.head);
+        launch_trace_occluded(st, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, v.head + 1, occ, cnt, v.list, v.head);
     } else {
         launch_trace_occluded(st, c->ds, rays, target, q, cursor, occ, cnt);
     }
@@ -841,19 +856,19 @@ bool trace_both(mipt_ctx* c, const float4* raysC, const int* indexC, QueueView q
                 const float4* raysO, const int* targetO, QueueView qO, unsigned* cursorO, unsigned char* occ) {
 #if PT_WIDE_K == 8
     if (c->useBitTrail || !(c->ds.nWide > 0 && c->useWide)) return false;
-    if (ensure_slow(c, c->slow, qC.space, c->stream) != MIPT_OK || ensure_slow(c, c->slowOcc, qO.space, c->stream) != MIPT_OK) return false;
+    SlowView vc{}, vo{};
+    if (ensure_slow(c, c->slow, c->slowParity, qC.space, c->stream, vc) != MIPT_OK ||
+        ensure_slow(c, c->slowOcc, c->slowOccParity, qO.space, c->stream, vo) != MIPT_OK) return false;
     count_launch(c, 0);
     count_launch(c, 1);
     unsigned long long* cntC = c->counting ? c->dTotals + 2 : nullptr;
     unsigned long long* cntO = c->counting ? c->dTotals + 4 : nullptr;
-    unsigned* sc = (unsigned*)c->slow.p;
-    unsigned* so = (unsigned*)c->slowOcc.p;
-    launch_trace_wide_both(c->stream, c->ds, raysC, indexC, qC, cursorC, hits, cntC, sc, (int*)(sc + kSlowHeader), raysO, targetO, qO, cursorO, occ,
-                           cntO, so, (int*)(so + kSlowHeader), c->shadowFirst ? 1 : 0);
-    if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, raysC, indexC, hits, cntC, (int*)(sc + kSlowHeader), sc);
-    launch_trace_closest(c->stream, c->ds, raysC, indexC, QueueView{nullptr, 0u, qC.space}, sc + 1, hits, cntC, (int*)(sc + kSlowHeader), sc);
-    if (!c->ds.drain) launch_trace_slow_occluded(c->stream, c->ds, raysO, targetO, occ, cntO, (int*)(so + kSlowHeader), so);
-    launch_trace_occluded(c->stream, c->ds, raysO, targetO, QueueView{nullptr, 0u, qO.space}, so + 1, occ, cntO, (int*)(so + kSlowHeader), so);
+    launch_trace_wide_both(c->stream, c->ds, raysC, indexC, qC, cursorC, hits, cntC, vc.head, vc.list, raysO, targetO, qO, cursorO, occ,
+                           cntO, vo.head, vo.list, c->shadowFirst ? 1 : 0, vc.next, vo.next);
+    if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, raysC, indexC, hits, cntC, vc.list, vc.head);
+    launch_trace_closest(c->stream, c->ds, raysC, indexC, QueueView{nullptr, 0u, qC.space}, vc.head + 1, hits, cntC, vc.list, vc.head);
+    if (!c->ds.drain) launch_trace_slow_occluded(c->stream, c->ds, raysO, targetO, occ, cntO, vo.list, vo.head);
+    launch_trace_occluded(c->stream, c->ds, raysO, targetO, QueueView{nullptr, 0u, qO.space}, vo.head + 1, occ, cntO, vo.list, vo.head);
     return true;
 #else
     return false;
@@ -1634,7 +1649,9 @@ static int ensure_path_buffers(mipt_ctx* c, size_t cap, size_t nPix) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = c->pathMem.ensure(o);
     if (rc != MIPT_OK) { c->pb.capacity = 0; c->pbPixels = 0; return rc; }
-    if ((rc = ensure_slow(c, c->slow, space, c->stream)) != MIPT_OK || (rc = ensure_slow(c, c->slowOcc, space * nl, c->stream)) != MIPT_OK) {
+    SlowView unused{};
+    if ((rc = ensure_slow(c, c->slow, c->slowParity, space, c->stream, unused, false)) != MIPT_OK ||
+        (rc = ensure_slow(c, c->slowOcc, c->slowOccParity, space * nl, c->stream, unused, false)) != MIPT_OK) {
         c->pb.capacity = 0; c->pbPixels = 0; return rc;
     }
     c->pbPixels = nPix;

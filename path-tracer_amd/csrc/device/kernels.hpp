@@ -89,15 +89,15 @@ void launch_trace_occluded(hipStream_t st, const DevScene& s, const float4* rays
 // the others are appended to slowList (count in *slowCount) for a literal walk afterwards
 void launch_trace_wide_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
                                unsigned* cursor, float4* hits, unsigned long long* counters, unsigned* slowCount,
-                               int* slowList);
+                               int* slowList, unsigned* nextHeader = nullptr);
 void launch_trace_wide_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
                                 unsigned* cursor, unsigned char* occ, unsigned long long* counters, unsigned* slowCount,
-                                int* slowList);
+                                int* slowList, unsigned* nextHeader = nullptr);
 // path mode: the extension rays (C) and the shadow rays (O) of one bounce in one launch; shadowFirst picks the order
 void launch_trace_wide_both(hipStream_t st, const DevScene& s, const float4* raysC, const int* indexC, QueueView qC, unsigned* cursorC,
                             float4* hits, unsigned long long* countersC, unsigned* slowCountC, int* slowListC, const float4* raysO,
                             const int* targetO, QueueView qO, unsigned* cursorO, unsigned char* occ, unsigned long long* countersO,
-                            unsigned* slowCountO, int* slowListO, int shadowFirst);
+                            unsigned* slowCountO, int* slowListO, int shadowFirst, unsigned* nextHeaderC, unsigned* nextHeaderO);
 void launch_trace_slow_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, float4* hits,
                                unsigned long long* counters, int* list, const unsigned* listCount);
 void launch_trace_slow_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, unsigned char* occ,

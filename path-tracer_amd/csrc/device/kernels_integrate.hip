@@ -460,14 +460,19 @@ __global__ __launch_bounds__(kBlock) void k_shade_b_direct(DevScene s, FramePara
     }
 }
 
-__global__ void k_fold_counters(const unsigned* __restrict__ counters, int nIter, unsigned long long* totals) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        unsigned long long e = 0, sh = 0;
-        for (int it = 0; it < nIter; it++)
-            for (int s = 0; s < kShards; s++) {
-                e += counters[counter_index(it, 0, s)];
-                sh += counters[counter_index(it, 2, s)];
-            }
+// one wavefront: lane = shard
+__global__ __launch_bounds__(64) void k_fold_counters(const unsigned* __restrict__ counters, int nIter, unsigned long long* totals) {
+    const int s = threadIdx.x;
+    unsigned long long e = 0, sh = 0;
+    for (int it = 0; it < nIter; it++) {
+        e += counters[counter_index(it, 0, s)];
+        sh += counters[counter_index(it, 2, s)];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        e += __shfl_down(e, off);
+        sh += __shfl_down(sh, off);
+    }
+    if (s == 0) {
         totals[0] += e;
         totals[1] += sh;
     }

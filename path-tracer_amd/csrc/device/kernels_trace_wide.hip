@@ -1116,8 +1116,11 @@ template <bool ANYHIT, bool COUNT>
 __global__ __launch_bounds__(WideCfg<ANYHIT>::kBlock) PT_WIDE_ATTR void k_trace_wide(
     DevScene s, const float4* __restrict__ rays, const int* __restrict__ index, const int* __restrict__ target,
     QueueView q, unsigned* __restrict__ cursor, float4* __restrict__ hits, unsigned char* __restrict__ occ,
-    unsigned long long* __restrict__ counters, unsigned* __restrict__ slowCount, int* __restrict__ slowList) {
+    unsigned long long* __restrict__ counters, unsigned* __restrict__ slowCount, int* __restrict__ slowList,
+    unsigned* __restrict__ nextHeader) {
     PT_WIDE_LDS_DECL(WideCfg<ANYHIT>::kBlock, WideCfg<ANYHIT>::kTop);
+    // the hand-back list's header for the NEXT launch on this list (two headers used in turn: no memset between launches)
+    if (nextHeader && blockIdx.x == 0 && threadIdx.x < 4) nextHeader[threadIdx.x] = 0u;
     const int nTop = s.nWideTop < WideCfg<ANYHIT>::kTop ? s.nWideTop : WideCfg<ANYHIT>::kTop;
     wide_load_top(s, ldsTop, nTop, WideCfg<ANYHIT>::kBlock);
     wide_prefix(q, ldsPrefix[0], 0, &ldsPool[0], ldsPoolCtl[0], WideCfg<ANYHIT>::kBlock / 64);
@@ -1142,8 +1145,13 @@ void k_trace_wide_both(DevScene s, const float4* __restrict__ raysC, const int* 
                        unsigned* __restrict__ slowCountC, int* __restrict__ slowListC,
                        const float4* __restrict__ raysO, const int* __restrict__ targetO, QueueView qO,
                        unsigned* __restrict__ cursorO, unsigned char* __restrict__ occ, unsigned long long* __restrict__ countersO,
-                       unsigned* __restrict__ slowCountO, int* __restrict__ slowListO, int shadowFirst) {
+                       unsigned* __restrict__ slowCountO, int* __restrict__ slowListO, int shadowFirst,
+                       unsigned* __restrict__ nextHeaderC, unsigned* __restrict__ nextHeaderO) {
     PT_WIDE_LDS_DECL(WideCfg<false>::kBlock, WideCfg<false>::kTop);
+    if (blockIdx.x == 0 && threadIdx.x < 4) {
+        if (nextHeaderC) nextHeaderC[threadIdx.x] = 0u;
+        if (nextHeaderO) nextHeaderO[threadIdx.x] = 0u;
+    }
     const int nTop = s.nWideTop < WideCfg<false>::kTop ? s.nWideTop : WideCfg<false>::kTop;
     wide_load_top(s, ldsTop, nTop, WideCfg<false>::kBlock);
     wide_prefix(qC, ldsPrefix[0], 0, &ldsPool[0], ldsPoolCtl[0], WideCfg<false>::kBlock / 64);
@@ -1170,39 +1178,39 @@ static inline unsigned wide_grid(size_t nMax) {
 }
 void launch_trace_wide_closest(hipStream_t st, const DevScene& s, const float4* rays, const int* index, QueueView q,
                                unsigned* cursor, float4* hits, unsigned long long* counters, unsigned* slowCount,
-                               int* slowList) {
+                               int* slowList, unsigned* nextHeader) {
     const unsigned g = wide_grid<false>(q.space);
     if (counters)
         hipLaunchKernelGGL((k_trace_wide<false, true>), dim3(g), dim3(WideCfg<false>::kBlock), 0, st, s, rays, index, nullptr, q, cursor,
-                           hits, nullptr, counters, slowCount, slowList);
+                           hits, nullptr, counters, slowCount, slowList, nextHeader);
     else
         hipLaunchKernelGGL((k_trace_wide<false, false>), dim3(g), dim3(WideCfg<false>::kBlock), 0, st, s, rays, index, nullptr, q, cursor,
-                           hits, nullptr, counters, slowCount, slowList);
+                           hits, nullptr, counters, slowCount, slowList, nextHeader);
 }
 void launch_trace_wide_occluded(hipStream_t st, const DevScene& s, const float4* rays, const int* target, QueueView q,
                                 unsigned* cursor, unsigned char* occ, unsigned long long* counters, unsigned* slowCount,
-                                int* slowList) {
+                                int* slowList, unsigned* nextHeader) {
     const unsigned g = wide_grid<true>(q.space);
     if (counters)
         hipLaunchKernelGGL((k_trace_wide<true, true>), dim3(g), dim3(WideCfg<true>::kBlock), 0, st, s, rays, nullptr, target, q, cursor,
-                           nullptr, occ, counters, slowCount, slowList);
+                           nullptr, occ, counters, slowCount, slowList, nextHeader);
     else
         hipLaunchKernelGGL((k_trace_wide<true, false>), dim3(g), dim3(WideCfg<true>::kBlock), 0, st, s, rays, nullptr, target, q, cursor,
-                           nullptr, occ, counters, slowCount, slowList);
+                           nullptr, occ, counters, slowCount, slowList, nextHeader);
 }
 
 #if PT_WIDE_K == 8
 void launch_trace_wide_both(hipStream_t st, const DevScene& s, const float4* raysC, const int* indexC, QueueView qC, unsigned* cursorC,
                             float4* hits, unsigned long long* countersC, unsigned* slowCountC, int* slowListC, const float4* raysO,
                             const int* targetO, QueueView qO, unsigned* cursorO, unsigned char* occ, unsigned long long* countersO,
-                            unsigned* slowCountO, int* slowListO, int shadowFirst) {
+                            unsigned* slowCountO, int* slowListO, int shadowFirst, unsigned* nextHeaderC, unsigned* nextHeaderO) {
     const unsigned g = wide_grid<false>((size_t)qC.space + qO.space);
     if (countersC)
         hipLaunchKernelGGL((k_trace_wide_both<true>), dim3(g), dim3(WideCfg<false>::kBlock), 0, st, s, raysC, indexC, qC, cursorC, hits,
-                           countersC, slowCountC, slowListC, raysO, targetO, qO, cursorO, occ, countersO, slowCountO, slowListO, shadowFirst);
+                           countersC, slowCountC, slowListC, raysO, targetO, qO, cursorO, occ, countersO, slowCountO, slowListO, shadowFirst, nextHeaderC, nextHeaderO);
     else
         hipLaunchKernelGGL((k_trace_wide_both<false>), dim3(g), dim3(WideCfg<false>::kBlock), 0, st, s, raysC, indexC, qC, cursorC, hits,
-                           countersC, slowCountC, slowListC, raysO, targetO, qO, cursorO, occ, countersO, slowCountO, slowListO, shadowFirst);
+                           countersC, slowCountC, slowListC, raysO, targetO, qO, cursorO, occ, countersO, slowCountO, slowListO, shadowFirst, nextHeaderC, nextHeaderO);
 }
 #endif
 
