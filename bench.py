@@ -323,8 +323,20 @@ def main():
         ctx.render_device(cam, p, accum2.data_ptr(), rgb2.data_ptr())
     ctx.synchronize()
     cnt = ctx.stats()
-    ctx.set_counting(False)
     assert cnt["rays_closest"] == st["rays_closest"] and cnt["rays_occluded"] == st["rays_occluded"]
+    # the same frames once more through the LITERAL threaded walk (k_trace, the reference's own tree and order): its node
+    # visits and triangle tests are the reference's per-ray work, a numerator that does not move when the product's own
+    # hierarchy does
+    ctx.reset_stats()
+    ctx.set_traversal(B.TRAVERSAL_THREADED)
+    for k in range(args.steps):
+        p = B.RenderParams(B.MODE_PATH, spp_per_step, first + k * spp_per_step, BOUNCES, SEED, rank, world, TILE_W, TILE_H)
+        ctx.render_device(cam, p, accum2.data_ptr(), rgb2.data_ptr())
+    ctx.synchronize()
+    ref_cnt = ctx.stats()
+    ctx.set_traversal(B.TRAVERSAL_DEFAULT)
+    ctx.set_counting(False)
+    assert ref_cnt["rays_closest"] == st["rays_closest"] and ref_cnt["rays_occluded"] == st["rays_occluded"]
     del accum2, rgb2
 
     weak = None
@@ -348,6 +360,10 @@ def main():
                          st["launches_closest"])
         ko = kernel_line(st["rays_occluded"], cnt["node_visits_occluded"], cnt["tri_tests_occluded"], st["ms_occluded"],
                          st["launches_occluded"])
+        kc_ref = kernel_line(st["rays_closest"], ref_cnt["node_visits_closest"], ref_cnt["tri_tests_closest"], st["ms_closest"],
+                             st["launches_closest"])
+        ko_ref = kernel_line(st["rays_occluded"], ref_cnt["node_visits_occluded"], ref_cnt["tri_tests_occluded"], st["ms_occluded"],
+                             st["launches_occluded"])
         # the kernel behind the two traversal entries: the order-free 4-wide traversal when the scene qualifies
         # (each launch is followed by a literal-walk launch over the handful of rays it handed back), else the walk
         tv = os.environ.get("MIPT_TRAVERSAL")  # A/B runs: walk = literal threaded walk, bittrail = StacklessBVH2 literal
@@ -355,7 +371,9 @@ def main():
         names = (("k_trace_wide_closest", "k_trace_wide_occluded") if wide else
                  ("k_trace_bittrail_closest", "k_trace_bittrail_occluded") if tv == "bittrail" else
                  ("k_trace_closest", "k_trace_occluded"))
-        dom, dom_name = (kc, names[0]) if st["ms_closest"] >= st["ms_occluded"] else (ko, names[1])
+        closest_dominates = st["ms_closest"] >= st["ms_occluded"]
+        dom, dom_name = (kc, names[0]) if closest_dominates else (ko, names[1])
+        dom_ref = kc_ref if closest_dominates else ko_ref
         # PMC counters of the dominant kernel (separate rocprofv3 --pmc passes, tools/pmc_passes.sh): reported only
         # when they were recorded for THESE kernel sources and this launch shape
         pmc, pmc_note = {}, None
@@ -372,6 +390,17 @@ def main():
             except Exception as e:
                 pmc_note = f"profiles/traffic.json unreadable: {e}"
         traffic = pmc.get("hbm_bytes_per_launch")
+        # the path-mode shading kernel: HBM-bound; bytes per launch from the same PMC passes, duration from this run's events
+        shade_pmc = allrec.get("k_shade_path", {}) if pmc else {}
+        shade_launches = int(st["launches_shade"])
+        shade_ms = st["ms_shade"] / max(shade_launches, 1)
+        shade_bytes = shade_pmc.get("hbm_bytes_per_launch")
+        k_shade = {"launches": shade_launches, "avg_launch_ms": shade_ms, "bound": "hbm",
+                   "hbm_bytes_per_launch": shade_bytes,
+                   "achieved_TBs": (shade_bytes / (shade_ms * 1e-3) / 1e12) if shade_bytes and shade_ms > 0 else None,
+                   "frac_of_hbm_peak": (shade_bytes / (shade_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if shade_bytes and shade_ms > 0 else None,
+                   "bytes_per_path_bounce": (shade_bytes * shade_launches / max(st["rays_closest"], 1)) if shade_bytes else None,
+                   "share_of_step": st["ms_shade"] / max(serial_elapsed * 1e3, 1e-9)}
         ms_frame = elapsed_max / args.steps * 1e3 / spp_per_step
         part = f"tiles {TILE_W}x{TILE_H} interleaved over {world} GPUs, one RCCL gather to rank 0 per step" if world > 1 else "one GPU"
         out = {
@@ -386,8 +415,11 @@ def main():
                        "rays_per_step": total_rays / args.steps, "ms_per_frame_1spp": ms_frame,
                        "ms_per_step_serialised_with_events": serial_elapsed / args.steps * 1e3,
                        "weak_scaling": weak},
-            "roofline": {"bound": "valu", "achieved": dom["achieved_TFLOPs"], "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom["achieved_TFLOPs"] / FP32_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": dom_name,
+            "roofline": {"bound": "valu", "achieved": dom_ref["achieved_TFLOPs"], "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom_ref["achieved_TFLOPs"] / FP32_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": dom_name,
+                         "flops_per_ray_reference_walk": dom_ref["algorithmic_flops_per_ray"],
+                         "achieved_own_tree": dom["achieved_TFLOPs"], "frac_own_tree": dom["achieved_TFLOPs"] / FP32_VALU_PEAK_TFLOPS,
+                         "flops_per_ray_own_tree": dom["algorithmic_flops_per_ray"],
                          "algorithmic_GBs": dom["achieved_GBs"],
                          "traffic_over_compulsory": (traffic / dom["compulsory_bytes_per_launch"]) if traffic else None,
                          "valu_issue_occupancy": pmc.get("valu_issue_occupancy"),
@@ -395,22 +427,33 @@ def main():
                          "lanes_per_valu_inst": pmc.get("lanes_per_valu_inst"), "l2_hit_rate": pmc.get("l2_hit_rate"),
                          "pmc_note": pmc_note,
                          "per_kernel": {"k_trace_closest": kc, "k_trace_occluded": ko, "kernel_names": list(names),
+                                        "k_shade_path": k_shade,
+                                        "reference_walk_counts": {"closest": {"node_visits_per_ray": kc_ref["node_visits_per_ray"],
+                                                                              "tri_tests_per_ray": kc_ref["tri_tests_per_ray"]},
+                                                                  "occluded": {"node_visits_per_ray": ko_ref["node_visits_per_ray"],
+                                                                               "tri_tests_per_ray": ko_ref["tri_tests_per_ray"]}},
                                         "other_ms_total": st["ms_other"], "other_launches": int(st["launches_other"])},
                          "note": "per-kernel durations come from a second pass over the same K steps (this rank) with HIP events "
-                                 "around every launch and the kernels serialised on one stream (config."
-                                 "ms_per_step_serialised_with_events); the timed loop overlaps shadow-ray and extension-ray "
-                                 "launches on two streams. achieved = algorithmic flops per launch (SURVEY 8(d): 27 per box test + 95 per triangle "
-                                 "test; box tests = 4 per visit of a 4-wide node + the exact test of each candidate leaf, "
-                                 "counted by the COUNT instantiation on the same frames) / average launch duration from "
-                                 "those HIP events, against the fp32 vector peak: the traversal is "
-                                 "bound by vector-ALU issue, not by HBM. -ffp-contract=off (bit-exactness) forbids FMA "
-                                 "in the tests, so at most half of that peak is reachable. algorithmic_GBs = SURVEY 8(d)'s "
-                                 "byte formula (48 B/ray + 32 B/box test + 36 B/triangle test) / the same duration: those "
+                                 "around every launch, one launch per traversal and all on one stream (config."
+                                 "ms_per_step_serialised_with_events); the timed loop traces a bounce's extension and shadow rays "
+                                 "in ONE launch (k_trace_wide_both). achieved / frac = the REFERENCE's work per ray -- node visits "
+                                 "and triangle tests of the literal threaded walk (StacklessBVH::intersect, counted by the COUNT "
+                                 "instantiation of k_trace on the same frames, outside the timed region) priced as SURVEY 8(d) "
+                                 "prices it, 27 flop per box test + 95 per triangle test -- x rays per launch / the average "
+                                 "duration of the launch that actually answers those rays (k_trace_wide), against the fp32 "
+                                 "vector peak: a figure only time can move. achieved_own_tree / frac_own_tree = the same with "
+                                 "the product's own counts (eight slot tests per visit of an eight-slot node + the exact test "
+                                 "of each candidate leaf): it rises when the product tests MORE boxes. The traversal is bound by "
+                                 "vector-ALU issue and by the latency of its own dependent loads, not by HBM; -ffp-contract=off "
+                                 "(bit-exactness) forbids FMA in the triangle test. algorithmic_GBs = SURVEY 8(d)'s byte formula "
+                                 "(48 B/ray + 32 B/box test + 36 B/triangle test, own-tree counts) / the same duration: those "
                                  "bytes are served by LDS / L1 / L2, not HBM, and may exceed the HBM peak. traffic = HBM-side "
                                  "bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE), "
                                  "traffic_over_compulsory = traffic / (52 B x rays). valu_issue_occupancy = VALU "
                                  "instructions x measured issue cost per instruction class / (SIMDs x kernel cycles); "
-                                 "useful_lane_frac = that x lanes_per_valu_inst / 64 (profiles/README.md)"},
+                                 "useful_lane_frac = that x lanes_per_valu_inst / 64 (profiles/README.md). per_kernel."
+                                 "k_shade_path: the HBM-bound shading kernel, PMC bytes per launch / its average launch "
+                                 "duration from this run's events against the 8 TB/s HBM3E peak"},
         }
         if world == 1 and args.with_primary:
             # primary-only rate of configs[0] (cornellbox 512x512, closest-hit ids), reported beside the

@@ -142,6 +142,9 @@ typedef struct mipt_stats {
     /* only with counting on: box tests (node visits) and triangle tests, per traversal kernel */
     uint64_t node_visits_closest, tri_tests_closest;
     uint64_t node_visits_occluded, tri_tests_occluded;
+    /* the path-mode shading kernel (k_shade_path), a subset of launches_other / ms_other */
+    uint64_t launches_shade;
+    double ms_shade;
 } mipt_stats;
 
 typedef struct mipt_mesh mipt_mesh;

@@ -61,7 +61,8 @@ class Stats(C.Structure):
                 ("launches_closest", C.c_uint64), ("launches_occluded", C.c_uint64), ("launches_other", C.c_uint64),
                 ("ms_closest", C.c_double), ("ms_occluded", C.c_double), ("ms_other", C.c_double),
                 ("node_visits_closest", C.c_uint64), ("tri_tests_closest", C.c_uint64),
-                ("node_visits_occluded", C.c_uint64), ("tri_tests_occluded", C.c_uint64)]
+                ("node_visits_occluded", C.c_uint64), ("tri_tests_occluded", C.c_uint64),
+                ("launches_shade", C.c_uint64), ("ms_shade", C.c_double)]
 
 
 # every symbol include/mipt.h declares (tests check the library exports all of them)

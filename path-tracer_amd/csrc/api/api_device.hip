@@ -774,7 +774,10 @@ struct Timer {
 void count_launch(mipt_ctx* c, int cls) {
     if (cls == 0) c->acc.launches_closest++;
     else if (cls == 1) c->acc.launches_occluded++;
-    else c->acc.launches_other++;
+    else {
+        c->acc.launches_other++;
+        if (cls == 3) c->acc.launches_shade++;
+    }
 }
 
 // cursor == nullptr: use (and zero) the context's own cursor word.
@@ -1351,7 +1354,10 @@ static int drain_timers(mipt_ctx* c) {
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
             if (t.cls == 0) c->acc.ms_closest += ms;
             else if (t.cls == 1) c->acc.ms_occluded += ms;
-            else c->acc.ms_other += ms;
+            else {
+                c->acc.ms_other += ms;
+                if (t.cls == 3) c->acc.ms_shade += ms;
+            }
         }
         c->freeEvents.push_back(t.a);
         c->freeEvents.push_back(t.b);
@@ -1768,8 +1774,8 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
             shadowsOwed = false;
             if (overlap && it > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->evOccluded[(size_t)it - 1], 0));  // shade(it) reads occ of bounce it-1
             {
-                Timer tm(c, 2);
-                count_launch(c, 2);
+                Timer tm(c, pathMode ? 3 : 2);
+                count_launch(c, pathMode ? 3 : 2);
                 if (pathMode) launch_shade_path(c->stream, c->ds, fp, pb, it, false);
                 else launch_shade_a(c->stream, c->ds, fp, pb, it);
             }

@@ -17,7 +17,9 @@ calls = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}", "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].split("::")[-1]
-        if "k_trace" in name:
+        if "k_trace_wide_both" in name:  # path mode's one launch per bounce (extension + shadow rays)
+            name = "k_trace_wide_both" + ("_count" if "<true>" in name else "")
+        elif "k_trace" in name:
             base = "k_trace_wide" if "k_trace_wide" in name else "k_trace"
             name = base + ("_occluded" if "<true" in name else "_closest") + ("_count" if ", true>" in name else "")
         agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -83,4 +85,12 @@ if "--traffic" in sys.argv:
                 if o.get("lanes_per_valu_inst"):
                     t[k]["lanes_per_valu_inst"] = o["lanes_per_valu_inst"]
                     t[k]["useful_lane_frac"] = t[k]["valu_issue_occupancy"] * o["lanes_per_valu_inst"] / 64.0
+    if "k_shade_path" in out and "hbm_read_bytes_per_launch" in out["k_shade_path"]:
+        o = out["k_shade_path"]
+        t["k_shade_path"] = {"hbm_read_bytes_per_launch": o["hbm_read_bytes_per_launch"],
+                             "hbm_write_bytes_per_launch": o.get("hbm_write_bytes_per_launch", 0.0),
+                             "hbm_bytes_per_launch": o["hbm_read_bytes_per_launch"] + o.get("hbm_write_bytes_per_launch", 0.0),
+                             "launches": o["launches"], "l2_hit_rate": o.get("l2_hit_rate"),
+                             "source": "as above; averaged over ALL launches of k_shade_path in the run (the finals-only launch "
+                                       "of every frame included)"}
     json.dump(t, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
