@@ -250,7 +250,23 @@ def main():
     # ---- scene: host-side load/build, then one arena upload ----
     arrays = sf.sponza_standin(args.detail)
     env = sf.procedural_env(1024)
-    scene = sf.product_scene_from_mesh_arrays(*arrays, env=env, lights=sf.SPONZA_LIGHT, all_axes=args.bvh == "all-axes")
+    # N ranks build ONE hierarchy: rank 0 builds it (on the host's cores) into a keyed file, the others load that file
+    # (mipt_scene_create_cached; the key covers the tree, the leaf order, the positions and the light)
+    wide_cache = None
+    if world > 1:
+        import tempfile
+        wide_cache = os.path.join(tempfile.gettempdir(), f"mipt_bench_{os.environ.get('MASTER_PORT', '0')}_{args.detail}_{args.bvh}.wide")
+    def make_scene():
+        return sf.product_scene_from_mesh_arrays(*arrays, env=env, lights=sf.SPONZA_LIGHT, all_axes=args.bvh == "all-axes", wide_cache=wide_cache)
+    t_scene = time.perf_counter()
+    if world > 1:
+        scene = make_scene() if rank == 0 else None
+        dist.barrier()
+        if rank != 0:
+            scene = make_scene()
+    else:
+        scene = make_scene()
+    t_scene = time.perf_counter() - t_scene
     stream = torch.cuda.current_stream(dev)
     ctx = B.Context(scene, device=local_rank, stream=stream.cuda_stream)
     cam = B.make_camera(W, H, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
@@ -413,6 +429,7 @@ def main():
                                    f"(uffizi_probe.hdr absent), {part}",
                        "bvh": args.bvh, "resolution": [W, H], "bounces": BOUNCES, "spp_per_step": spp_per_step, "seed": SEED,
                        "rays_per_step": total_rays / args.steps, "ms_per_frame_1spp": ms_frame,
+                       "scene_create_s": t_scene,
                        "ms_per_step_serialised_with_events": serial_elapsed / args.steps * 1e3,
                        "weak_scaling": weak},
             "roofline": {"bound": "valu", "achieved": dom_ref["achieved_TFLOPs"], "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

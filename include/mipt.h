@@ -252,6 +252,14 @@ int mipt_scene_desc_fill(const mipt_mesh* mesh, const mipt_bvh* bvh, const mipt_
 
 /* Validates and COPIES the description (caller may free its arrays at once). */
 int mipt_scene_create(const mipt_scene_desc* desc, mipt_scene** out);
+/* mipt_scene_create with the library's own hierarchy above the leaves kept in a file (no counterpart in the reference,
+ * whose start pays BVH::build every time, cs488.h:1562-1595, and whose CUDA program copies the tree node by node,
+ * gpu/src/cs488.h:2442-2460): when wide_cache_path holds the hierarchy built from exactly these nodes, leaf order, triangle
+ * positions, lights and build switches (a 64-bit key over them, layout constants and a checksum are checked), it is
+ * loaded -- the same arrays bit for bit -- else it is built (on the host's cores) and written there.  An unreadable,
+ * foreign or damaged file is ignored and overwritten; a file that cannot be written is not an error.  Every rank of a
+ * multi-GPU run and every start of mipt_render --cache uses this.  NULL or "": as mipt_scene_create. */
+int mipt_scene_create_cached(const mipt_scene_desc* desc, const char* wide_cache_path, mipt_scene** out);
 void mipt_scene_destroy(mipt_scene*);
 /* 1 when every box plane of the scene is 0 or of magnitude in [2^-61, 2^40] (and min <= max), so the traversal
  * kernel may replace the six IEEE divisions of AABB::intersect (C:574-580) by its exact per-ray reciprocal
@@ -264,6 +272,10 @@ int mipt_scene_exact_reciprocal(const mipt_scene*);
  * StacklessBVH::intersect (C:1661-1683).  The depth of the given tree does not matter.  Results are bit-identical
  * either way.  No counterpart in the reference. */
 int mipt_scene_wide_nodes(const mipt_scene*);
+/* 64-bit FNV-1a over the arrays of that tree as the GPU will read them (nodes, exact leaf boxes, leaf heads, scale): two
+ * scenes with the same value walk the same hierarchy -- what a test of mipt_scene_create_cached, or of a build on
+ * another number of threads, compares.  No counterpart in the reference. */
+uint64_t mipt_scene_wide_hash(const mipt_scene*);
 /* Host-side check (no GPU) of what the order-free traversal rests on: the 4-wide tree -- a hierarchy of the library's
  * own over the reference's LEAVES, see DESIGN.md 4 -- reaches every leaf exactly once, and every slot's stored box
  * contains everything stored below it, down to the leaf's exact box.  MIPT_OK (with the number of leaves and the

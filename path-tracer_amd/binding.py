@@ -79,7 +79,7 @@ SYMBOLS = [
     "mipt_bvh_node_min", "mipt_bvh_node_max", "mipt_bvh_id_hit", "mipt_bvh_id_miss", "mipt_bvh_leaf_first",
     "mipt_bvh_leaf_count", "mipt_bvh_id_left", "mipt_bvh_id_right", "mipt_bvh_id_parent", "mipt_bvh_id_sibling",
     "mipt_bvh_tri_index", "mipt_bvh_destroy",
-    "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_destroy", "mipt_scene_exact_reciprocal", "mipt_scene_wide_nodes", "mipt_scene_selfcheck_wide",
+    "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_create_cached", "mipt_scene_destroy", "mipt_scene_exact_reciprocal", "mipt_scene_wide_nodes", "mipt_scene_wide_hash", "mipt_scene_selfcheck_wide",
     "mipt_context_create", "mipt_context_destroy", "mipt_context_arena_bytes",
     "mipt_trace", "mipt_trace_device", "mipt_trace_device_noalloc", "mipt_occluded", "mipt_eye_rays", "mipt_background",
     "mipt_selftest_fast_division", "mipt_selftest_vec_ops", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
@@ -158,6 +158,9 @@ def lib():
     L.mipt_scene_selfcheck_wide.restype = C.c_int32
     L.mipt_scene_desc_fill.argtypes = [vp, vp, vp, C.POINTER(Light), C.c_int32, C.POINTER(SceneDesc)]
     L.mipt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
+    L.mipt_scene_create_cached.argtypes = [C.POINTER(SceneDesc), C.c_char_p, C.POINTER(vp)]
+    L.mipt_scene_wide_hash.argtypes = [vp]
+    L.mipt_scene_wide_hash.restype = C.c_uint64
     L.mipt_context_create.argtypes = [vp, C.c_int, vp, C.POINTER(vp)]
     L.mipt_context_arena_bytes.argtypes = [vp]
     L.mipt_context_arena_bytes.restype = C.c_size_t
@@ -465,7 +468,8 @@ def file_fingerprint(path):
 class Scene:
     """Scene of the reference (C:2004-2036): one object, lights, background."""
 
-    def __init__(self, mesh, bvh=None, env=None, lights=((3.0, 3.0, 3.0, 1000.0, 1000.0, 1000.0),)):
+    def __init__(self, mesh, bvh=None, env=None, lights=((3.0, 3.0, 3.0, 1000.0, 1000.0, 1000.0),), wide_cache=None):
+        """wide_cache: path of a file that keeps the library's own hierarchy above the leaves (mipt_scene_create_cached)"""
         self.mesh = mesh
         self.bvh = bvh if bvh is not None else BVH(mesh)
         self.env = env
@@ -477,8 +481,16 @@ class Scene:
         check(lib().mipt_scene_desc_fill(mesh.h, self.bvh.h, env.h if env is not None else None, self.lights,
                                          len(lights), C.byref(self.desc)))
         h = C.c_void_p()
-        check(lib().mipt_scene_create(C.byref(self.desc), C.byref(h)))
+        if wide_cache:
+            check(lib().mipt_scene_create_cached(C.byref(self.desc), os.fsencode(wide_cache), C.byref(h)))
+        else:
+            check(lib().mipt_scene_create(C.byref(self.desc), C.byref(h)))
         self.h = h
+
+    @property
+    def wide_hash(self):
+        """FNV-1a of the wide tree's arrays as the GPU reads them (mipt_scene_wide_hash)"""
+        return int(lib().mipt_scene_wide_hash(self.h))
 
     @property
     def exact_reciprocal(self):

@@ -7,7 +7,11 @@
 #include <cfloat>
 #include <cmath>
 #include <algorithm>
+#include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <thread>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <queue>
@@ -187,52 +191,77 @@ static void rebuild_top(const mipt_scene_desc* d, BinTree& t) {
         for (int a = 0; a < 3; a++) { if (l.lo[a] < lo[a]) lo[a] = l.lo[a]; if (l.hi[a] > hi[a]) hi[a] = l.hi[a]; }
     };
     struct Job { int begin, end, node; };
-    std::vector<Job> jobs;
-    std::vector<double> rightArea;
-    std::vector<long long> rightW;
-    std::vector<int> best, tmp;
+    struct Scratch { std::vector<double> rightArea; std::vector<long long> rightW; std::vector<int> best, tmp; bool wide = false; };
     auto boxOf = [&](int begin, int end, float* lo, float* hi) {
         for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
         for (int k = begin; k < end; k++) grow(lo, hi, leaves[(size_t)idx[(size_t)k]]);
     };
-    {
-        float lo[3], hi[3];
-        boxOf(0, nl, lo, hi);
-        if (nl == 1) { t.add(lo, hi, leaves[0].ref); return; }
-        jobs.push_back({0, nl, t.add(lo, hi, -1)});
-    }
-    while (!jobs.empty()) {
-        const Job j = jobs.back();
-        jobs.pop_back();
+    // one node: the cheapest split over the three axes, its two children added to `tree`, the interior ones pushed on `jobs`
+    auto splitJob = [&](const Job j, BinTree& tree, std::vector<Job>& jobs, Scratch& sc) {
         const int cnt = j.end - j.begin;
         double bestCost = INFINITY;
         int bestSplit = -1, bestAxis = -1;
+        if (cnt >= 16384 && sc.wide) {  // a big range near the root: its three axes on three threads, the same choice
+            struct AxisBest { double cost = INFINITY; int split = -1; std::vector<int> order; };
+            AxisBest ab[3];
+            auto sweep = [&](int axis) {
+                AxisBest& r = ab[axis];
+                r.order.assign(idx.begin() + j.begin, idx.begin() + j.end);
+                std::sort(r.order.begin(), r.order.end(), [&](int x, int y) {
+                    const float cx = leaves[(size_t)x].c[axis], cy = leaves[(size_t)y].c[axis];
+                    return cx < cy || (cx == cy && x < y);
+                });
+                std::vector<double> ra((size_t)cnt + 1, 0.0);
+                std::vector<long long> rw((size_t)cnt + 1, 0);
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int k = cnt - 1; k > 0; k--) {
+                    grow(lo, hi, leaves[(size_t)r.order[(size_t)k]]);
+                    ra[(size_t)k] = area(lo, hi);
+                    rw[(size_t)k] = rw[(size_t)k + 1] + leaves[(size_t)r.order[(size_t)k]].w;
+                }
+                for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+                long long wl = 0;
+                for (int k = 1; k < cnt; k++) {
+                    grow(lo, hi, leaves[(size_t)r.order[(size_t)k - 1]]);
+                    wl += leaves[(size_t)r.order[(size_t)k - 1]].w;
+                    const double cost = area(lo, hi) * (double)wl + ra[(size_t)k] * (double)rw[(size_t)k];
+                    if (cost < r.cost) { r.cost = cost; r.split = k; }
+                }
+            };
+            std::thread ty(sweep, 1), tz(sweep, 2);
+            sweep(0);
+            ty.join();
+            tz.join();
+            for (int axis = 0; axis < 3; axis++)  // strictly cheaper wins, in axis order: what the loop below does
+                if (ab[axis].cost < bestCost) { bestCost = ab[axis].cost; bestSplit = ab[axis].split; bestAxis = axis; }
+            if (bestAxis >= 0) sc.best.swap(ab[bestAxis].order);
+        } else
         for (int axis = 0; axis < 3; axis++) {
-            tmp.assign(idx.begin() + j.begin, idx.begin() + j.end);
-            std::sort(tmp.begin(), tmp.end(), [&](int x, int y) {
+            sc.tmp.assign(idx.begin() + j.begin, idx.begin() + j.end);
+            std::sort(sc.tmp.begin(), sc.tmp.end(), [&](int x, int y) {
                 const float cx = leaves[(size_t)x].c[axis], cy = leaves[(size_t)y].c[axis];
                 return cx < cy || (cx == cy && x < y);
             });
-            rightArea.assign((size_t)cnt + 1, 0.0);
-            rightW.assign((size_t)cnt + 1, 0);
+            sc.rightArea.assign((size_t)cnt + 1, 0.0);
+            sc.rightW.assign((size_t)cnt + 1, 0);
             float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
             for (int k = cnt - 1; k > 0; k--) {
-                grow(lo, hi, leaves[(size_t)tmp[(size_t)k]]);
-                rightArea[(size_t)k] = area(lo, hi);
-                rightW[(size_t)k] = rightW[(size_t)k + 1] + leaves[(size_t)tmp[(size_t)k]].w;
+                grow(lo, hi, leaves[(size_t)sc.tmp[(size_t)k]]);
+                sc.rightArea[(size_t)k] = area(lo, hi);
+                sc.rightW[(size_t)k] = sc.rightW[(size_t)k + 1] + leaves[(size_t)sc.tmp[(size_t)k]].w;
             }
             for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
             long long wl = 0;
             for (int k = 1; k < cnt; k++) {  // split before position k: [0, k) | [k, cnt)
-                grow(lo, hi, leaves[(size_t)tmp[(size_t)k - 1]]);
-                wl += leaves[(size_t)tmp[(size_t)k - 1]].w;
-                const double cost = area(lo, hi) * (double)wl + rightArea[(size_t)k] * (double)rightW[(size_t)k];
+                grow(lo, hi, leaves[(size_t)sc.tmp[(size_t)k - 1]]);
+                wl += leaves[(size_t)sc.tmp[(size_t)k - 1]].w;
+                const double cost = area(lo, hi) * (double)wl + sc.rightArea[(size_t)k] * (double)sc.rightW[(size_t)k];
                 if (cost < bestCost) { bestCost = cost; bestSplit = k; bestAxis = axis; }
             }
-            if (bestAxis == axis) best.swap(tmp);  // keep the order of the axis that holds the best split so far
+            if (bestAxis == axis) sc.best.swap(sc.tmp);  // keep the order of the axis that holds the best split so far
         }
-        if (bestSplit < 0) { bestSplit = cnt / 2; best.assign(idx.begin() + j.begin, idx.begin() + j.end); }  // NaN-free input never gets here
-        std::copy(best.begin(), best.end(), idx.begin() + j.begin);
+        if (bestSplit < 0) { bestSplit = cnt / 2; sc.best.assign(idx.begin() + j.begin, idx.begin() + j.end); }  // NaN-free input never gets here
+        std::copy(sc.best.begin(), sc.best.end(), idx.begin() + j.begin);
         const int mid = j.begin + bestSplit;
         int child[2];
         const int range[2][2] = {{j.begin, mid}, {mid, j.end}};
@@ -240,11 +269,72 @@ static void rebuild_top(const mipt_scene_desc* d, BinTree& t) {
             float lo[3], hi[3];
             boxOf(range[side][0], range[side][1], lo, hi);
             const bool leaf = range[side][1] - range[side][0] == 1;
-            child[side] = t.add(lo, hi, leaf ? leaves[(size_t)idx[(size_t)range[side][0]]].ref : -1);
+            child[side] = tree.add(lo, hi, leaf ? leaves[(size_t)idx[(size_t)range[side][0]]].ref : -1);
             if (!leaf) jobs.push_back({range[side][0], range[side][1], child[side]});
         }
-        t.left[(size_t)j.node] = child[0];
-        t.right[(size_t)j.node] = child[1];
+        tree.left[(size_t)j.node] = child[0];
+        tree.right[(size_t)j.node] = child[1];
+    };
+    std::vector<Job> jobs;
+    Scratch sc0;
+    sc0.wide = true;  // the sequential top of the tree may put a node's three axes on three threads
+    {
+        float lo[3], hi[3];
+        boxOf(0, nl, lo, hi);
+        if (nl == 1) { t.add(lo, hi, leaves[0].ref); return; }
+        jobs.push_back({0, nl, t.add(lo, hi, -1)});
+    }
+    // Round 3: the top of the tree one node at a time, largest range first, until there are 64 ranges; those are
+    // independent (disjoint ranges of idx), so each is built into a tree of its own by whichever thread is free and the
+    // pieces are appended in range order: the result does not depend on the threads.
+    if (nl >= 4096) {
+        while (jobs.size() < 64) {
+            size_t big = 0;
+            for (size_t k = 1; k < jobs.size(); k++)
+                if (jobs[k].end - jobs[k].begin > jobs[big].end - jobs[big].begin) big = k;
+            const Job j = jobs[big];
+            jobs.erase(jobs.begin() + (long)big);
+            splitJob(j, t, jobs, sc0);
+        }
+        std::sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return a.begin < b.begin; });
+        std::vector<BinTree> piece(jobs.size());
+        unsigned nThreads = std::thread::hardware_concurrency();
+        nThreads = nThreads < 1 ? 1 : (nThreads > 16 ? 16 : nThreads);
+        if (const char* tv = getenv("MIPT_BUILD_THREADS")) nThreads = (unsigned)std::max(1, atoi(tv));
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            Scratch sc;
+            std::vector<Job> mine;
+            for (size_t k = next.fetch_add(1); k < jobs.size(); k = next.fetch_add(1)) {
+                BinTree& lt = piece[k];
+                float lo[3], hi[3];
+                boxOf(jobs[k].begin, jobs[k].end, lo, hi);
+                mine.assign(1, Job{jobs[k].begin, jobs[k].end, lt.add(lo, hi, -1)});  // local node 0 stands for jobs[k].node
+                while (!mine.empty()) {
+                    const Job j = mine.back();
+                    mine.pop_back();
+                    splitJob(j, lt, mine, sc);
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned k = 1; k < nThreads; k++) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+        for (size_t k = 0; k < jobs.size(); k++) {
+            const BinTree& lt = piece[k];
+            const int base = t.size() - 1;  // local node i >= 1 becomes base + i
+            for (int i = 1; i < lt.size(); i++) t.add(&lt.mn[3 * (size_t)i], &lt.mx[3 * (size_t)i], lt.refLeaf[(size_t)i]);
+            auto g = [&](int i) { return i == 0 ? jobs[k].node : base + i; };
+            for (int i = 0; i < lt.size(); i++)
+                if (lt.refLeaf[(size_t)i] < 0) { t.left[(size_t)g(i)] = g(lt.left[(size_t)i]); t.right[(size_t)g(i)] = g(lt.right[(size_t)i]); }
+        }
+        return;
+    }
+    while (!jobs.empty()) {
+        const Job j = jobs.back();
+        jobs.pop_back();
+        splitJob(j, t, jobs, sc0);
     }
 }
 
@@ -254,13 +344,19 @@ static void rebuild_top(const mipt_scene_desc* d, BinTree& t) {
 // it was is one of the candidates, so the sum of interior box areas -- the expected number of node visits -- never
 // grows.  Nodes are tried largest box first, in passes, until a pass gains under half a per cent.  Afterwards the
 // nodes are renumbered parents first (the collapse sweeps rely on children having larger ids).
+// Round 3: the passes run per SUBTREE, the subtrees in parallel.  The tree is cut below its top (the largest subtree is
+// opened until there are 64 of them, or fewer for small trees); a subtree keeps its leaves, so the box of its root
+// -- whichever node ends up there -- stays what it was and the nodes above the cut are untouched.  What is lost are moves
+// ACROSS the cut (after an all-axes SAH build there are few: measured below); what is gained is the host's cores, the
+// pass over the 92,501 nodes of the bench scene being the bulk of mipt_scene_create.  Each subtree is worked on by one
+// thread with its own passes and its own stopping rule, and no thread touches another's nodes: the result does not
+// depend on the number of threads or on their timing.
 static void optimise_top(BinTree& t) {
     const int n = t.size();
     if (n < 7 || n > 2000000) return;  // nothing to move / more than a million leaves: the passes would take minutes, the SAH build alone has to do
     std::vector<int> parent((size_t)n, -1);
     for (int i = 0; i < n; i++)
         if (t.refLeaf[(size_t)i] < 0) { parent[(size_t)t.left[(size_t)i]] = i; parent[(size_t)t.right[(size_t)i]] = i; }
-    int root = 0;
     auto areaOf = [&](int v) -> double {
         const double ex = (double)t.mx[3 * (size_t)v] - t.mn[3 * (size_t)v], ey = (double)t.mx[3 * (size_t)v + 1] - t.mn[3 * (size_t)v + 1],
                      ez = (double)t.mx[3 * (size_t)v + 2] - t.mn[3 * (size_t)v + 2];
@@ -272,7 +368,7 @@ static void optimise_top(BinTree& t) {
             e[k] = (double)std::max(t.mx[3 * (size_t)a + k], t.mx[3 * (size_t)b + k]) - std::min(t.mn[3 * (size_t)a + k], t.mn[3 * (size_t)b + k]);
         return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
     };
-    auto refit = [&](int v) {  // v and its ancestors: box = union of the children's
+    auto refit = [&](int v) {  // v and its ancestors up to the root of its subtree: box = union of the children's
         for (; v >= 0; v = parent[(size_t)v]) {
             const int l = t.left[(size_t)v], r = t.right[(size_t)v];
             for (int k = 0; k < 3; k++) {
@@ -281,58 +377,142 @@ static void optimise_top(BinTree& t) {
             }
         }
     };
-    auto total = [&]() { double c = 0.0; for (int i = 0; i < n; i++) if (t.refLeaf[(size_t)i] < 0) c += areaOf(i); return c; };
-    std::vector<int> order((size_t)n);
-    std::priority_queue<std::pair<double, int>> pq;  // (-induced cost, node)
-    double before = total();
-    for (int pass = 0; pass < 8; pass++) {
-        for (int i = 0; i < n; i++) order[(size_t)i] = i;
-        std::vector<double> key((size_t)n);
-        for (int i = 0; i < n; i++) key[(size_t)i] = areaOf(i);
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return key[(size_t)a] > key[(size_t)b] || (key[(size_t)a] == key[(size_t)b] && a < b); });
-        for (const int N : order) {
-            const int P = parent[(size_t)N];
-            if (P < 0) continue;                         // the root stays
-            const int G = parent[(size_t)P];
-            if (G < 0 && t.refLeaf[(size_t)(t.left[(size_t)P] == N ? t.right[(size_t)P] : t.left[(size_t)P])] >= 0) continue;  // two nodes left: nothing to choose
-            const int S = t.left[(size_t)P] == N ? t.right[(size_t)P] : t.left[(size_t)P];
-            // take N (and P) out
-            parent[(size_t)S] = G;
-            if (G < 0) root = S;
-            else {
-                if (t.left[(size_t)G] == P) t.left[(size_t)G] = S; else t.right[(size_t)G] = S;
-                refit(G);
-            }
-            // where does N go back?
-            const double aN = areaOf(N);
-            double best = INFINITY;
-            int bestX = S;
-            while (!pq.empty()) pq.pop();
-            pq.push({-0.0, root});
-            while (!pq.empty()) {
-                const double ci = -pq.top().first;
-                const int X = pq.top().second;
-                pq.pop();
-                if (ci + aN >= best) break;
-                const double ct = ci + unionArea(X, N);
-                if (ct < best) { best = ct; bestX = X; }
-                if (t.refLeaf[(size_t)X] < 0) {
-                    const double cc = ct - areaOf(X);
-                    if (cc + aN < best) { pq.push({-cc, t.left[(size_t)X]}); pq.push({-cc, t.right[(size_t)X]}); }
-                }
-            }
-            // P becomes the parent of bestX and N, in bestX's place
-            const int X = bestX, XP = parent[(size_t)X];
-            t.left[(size_t)P] = X; t.right[(size_t)P] = N;
-            parent[(size_t)X] = P; parent[(size_t)N] = P; parent[(size_t)P] = XP;
-            if (XP < 0) root = P;
-            else if (t.left[(size_t)XP] == X) t.left[(size_t)XP] = P; else t.right[(size_t)XP] = P;
-            refit(P);
+    // the cut: open the subtree with the most nodes until there are enough of them (sizes by a sweep over the children-
+    // after-parents numbering both inputs have)
+    std::vector<int> size((size_t)n, 1);
+    for (int i = n - 1; i >= 0; i--)
+        if (t.refLeaf[(size_t)i] < 0) size[(size_t)i] = 1 + size[(size_t)t.left[(size_t)i]] + size[(size_t)t.right[(size_t)i]];
+    const bool stats = getenv("MIPT_WIDE_STATS") != nullptr;
+    double areaBefore = 0.0;
+    if (stats) for (int i = 0; i < n; i++) if (t.refLeaf[(size_t)i] < 0) areaBefore += areaOf(i);
+    int root = 0;
+    // two rounds: 64 subtrees (cheap: small search spaces), then 16 with at most two passes each, which lets nodes cross
+    // the first round's cuts
+    const int nPhases = n < 8192 ? 1 : 2;
+    for (int phase = 0; phase < nPhases; phase++) {
+    const int maxPasses = phase == 0 ? 8 : 2;
+    if (phase > 0) {  // sizes of the tree as it stands (ids are no longer parents-first: walk it)
+        std::vector<int> order, st{root};
+        while (!st.empty()) {
+            const int v = st.back();
+            st.pop_back();
+            order.push_back(v);
+            if (t.refLeaf[(size_t)v] < 0) { st.push_back(t.left[(size_t)v]); st.push_back(t.right[(size_t)v]); }
         }
-        const double after = total();
-        const bool done = !(after < before * 0.995);
-        before = after;
-        if (done) break;
+        for (size_t k = order.size(); k-- > 0;) {
+            const int v = order[k];
+            size[(size_t)v] = t.refLeaf[(size_t)v] < 0 ? 1 + size[(size_t)t.left[(size_t)v]] + size[(size_t)t.right[(size_t)v]] : 1;
+        }
+    }
+    std::vector<int> roots{root};
+    const size_t wanted = n < 8192 ? 1 : (phase == 0 ? 64 : 16);
+    while (roots.size() < wanted) {
+        size_t big = 0;
+        for (size_t k = 1; k < roots.size(); k++)
+            if (size[(size_t)roots[k]] > size[(size_t)roots[big]]) big = k;
+        const int v = roots[big];
+        if (t.refLeaf[(size_t)v] >= 0 || size[(size_t)v] < 64) break;
+        roots[big] = t.left[(size_t)v];
+        roots.push_back(t.right[(size_t)v]);
+    }
+    std::sort(roots.begin(), roots.end(), [&](int a, int b) { return size[(size_t)a] > size[(size_t)b] || (size[(size_t)a] == size[(size_t)b] && a < b); });
+
+    // one subtree: detached from its parent while it is worked on, hung back (under whichever node is its root then) after
+    auto optimiseSubtree = [&](const int R) {
+        const int up = parent[(size_t)R];
+        const bool wasLeft = up >= 0 && t.left[(size_t)up] == R;
+        parent[(size_t)R] = -1;
+        int root = R;
+        std::vector<int> nodes;  // the subtree's nodes: the set stays, the shape changes
+        {
+            std::vector<int> st{R};
+            while (!st.empty()) {
+                const int v = st.back();
+                st.pop_back();
+                nodes.push_back(v);
+                if (t.refLeaf[(size_t)v] < 0) { st.push_back(t.right[(size_t)v]); st.push_back(t.left[(size_t)v]); }
+            }
+        }
+        if (nodes.size() >= 7) {
+            auto total = [&]() { double c = 0.0; for (const int i : nodes) if (t.refLeaf[(size_t)i] < 0) c += areaOf(i); return c; };
+            std::vector<std::pair<double, int>> keyed(nodes.size());
+            std::priority_queue<std::pair<double, int>> pq;  // (-induced cost, node)
+            double before = total();
+            for (int pass = 0; pass < maxPasses; pass++) {
+                for (size_t i = 0; i < nodes.size(); i++) keyed[i] = {areaOf(nodes[i]), nodes[i]};
+                std::sort(keyed.begin(), keyed.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+                    return a.first > b.first || (a.first == b.first && a.second < b.second);
+                });
+                for (const auto& kn : keyed) {
+                    const int N = kn.second;
+                    const int P = parent[(size_t)N];
+                    if (P < 0) continue;                         // the root stays
+                    const int G = parent[(size_t)P];
+                    if (G < 0 && t.refLeaf[(size_t)(t.left[(size_t)P] == N ? t.right[(size_t)P] : t.left[(size_t)P])] >= 0) continue;  // two nodes left: nothing to choose
+                    const int S = t.left[(size_t)P] == N ? t.right[(size_t)P] : t.left[(size_t)P];
+                    // take N (and P) out
+                    parent[(size_t)S] = G;
+                    if (G < 0) root = S;
+                    else {
+                        if (t.left[(size_t)G] == P) t.left[(size_t)G] = S; else t.right[(size_t)G] = S;
+                        refit(G);
+                    }
+                    // where does N go back?
+                    const double aN = areaOf(N);
+                    double best = INFINITY;
+                    int bestX = S;
+                    while (!pq.empty()) pq.pop();
+                    pq.push({-0.0, root});
+                    while (!pq.empty()) {
+                        const double ci = -pq.top().first;
+                        const int X = pq.top().second;
+                        pq.pop();
+                        if (ci + aN >= best) break;
+                        const double ct = ci + unionArea(X, N);
+                        if (ct < best) { best = ct; bestX = X; }
+                        if (t.refLeaf[(size_t)X] < 0) {
+                            const double cc = ct - areaOf(X);
+                            if (cc + aN < best) { pq.push({-cc, t.left[(size_t)X]}); pq.push({-cc, t.right[(size_t)X]}); }
+                        }
+                    }
+                    // P becomes the parent of bestX and N, in bestX's place
+                    const int X = bestX, XP = parent[(size_t)X];
+                    t.left[(size_t)P] = X; t.right[(size_t)P] = N;
+                    parent[(size_t)X] = P; parent[(size_t)N] = P; parent[(size_t)P] = XP;
+                    if (XP < 0) root = P;
+                    else if (t.left[(size_t)XP] == X) t.left[(size_t)XP] = P; else t.right[(size_t)XP] = P;
+                    refit(P);
+                }
+                const double after = total();
+                const bool done = !(after < before * 0.995);
+                before = after;
+                if (done) break;
+            }
+        }
+        parent[(size_t)root] = up;
+        if (up >= 0) { if (wasLeft) t.left[(size_t)up] = root; else t.right[(size_t)up] = root; }
+        return root;
+    };
+    if (roots.size() == 1) {
+        root = optimiseSubtree(root);
+    } else {
+        unsigned nThreads = std::thread::hardware_concurrency();
+        nThreads = nThreads < 1 ? 1 : (nThreads > 16 ? 16 : nThreads);
+        if (const char* tv = getenv("MIPT_BUILD_THREADS")) nThreads = (unsigned)std::max(1, atoi(tv));
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t k = next.fetch_add(1); k < roots.size(); k = next.fetch_add(1)) (void)optimiseSubtree(roots[k]);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned k = 1; k < nThreads; k++) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+    }
+    }  // phases
+    if (stats) {
+        double areaAfter = 0.0;
+        for (int i = 0; i < n; i++) if (t.refLeaf[(size_t)i] < 0) areaAfter += areaOf(i);
+        fprintf(stderr, "optimise_top: sum of interior areas %.6g -> %.6g\n", areaBefore, areaAfter);
     }
     // renumber: parents before children, root = 0
     BinTree o;
@@ -388,8 +568,13 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
             if (!seen[i]) return false;
         if (rebuilt) {
             bt = BinTree();
+            const auto t0 = std::chrono::steady_clock::now();
             rebuild_top(d, bt);
+            const auto t1 = std::chrono::steady_clock::now();
             if (top > 1) optimise_top(bt);
+            if (getenv("MIPT_WIDE_STATS"))
+                fprintf(stderr, "build_wide: SAH over the leaves %.3f s, insertion optimisation %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
         }
     }
     const int n = bt.size();
@@ -894,11 +1079,101 @@ int make_camera(const mipt_camera* cam, CameraDev& out) {
     return MIPT_OK;
 }
 
+// ---- the wide hierarchy on disk (mipt_scene_create_cached) ----
+// build_wide is a function of the tree, the leaf order, the triangle positions (leafHead), the lights (slot order) and the
+// build's switches; the file holds its output under a 64-bit FNV-1a key over exactly those, and is used only when the key,
+// the layout constants and its own checksum all agree.  Written to a temporary name and renamed, so that ranks racing
+// for one path read either nothing or a whole file.
+constexpr unsigned kWideCacheVersion = 3;
+struct Fnv {
+    unsigned long long h = 1469598103934665603ull;
+    void add(const void* p, size_t n) {
+        const unsigned char* b = (const unsigned char*)p;
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    }
+    template <class T> void pod(const T& v) { add(&v, sizeof v); }
+};
+unsigned long long wide_key(const mipt_scene_desc* d, int mode, int top) {
+    Fnv f;
+    f.pod(kWideCacheVersion); f.pod(ptd::kWideK); f.pod(ptd::kWideNodeStrideF4); f.pod(ptd::kLeafHeadStrideF4); f.pod(ptd::kWideMaxDepth);
+    f.pod(mode); f.pod(top);
+    const char* so = getenv("MIPT_WIDE_SLOT_ORDER");
+    if (so) f.add(so, strlen(so));
+    f.pod(d->n_nodes); f.pod(d->n_tri_index); f.pod(d->n_tris); f.pod(d->n_lights);
+    f.add(d->node_min, sizeof(float) * 3 * (size_t)d->n_nodes); f.add(d->node_max, sizeof(float) * 3 * (size_t)d->n_nodes);
+    f.add(d->id_hit, sizeof(int) * (size_t)d->n_nodes); f.add(d->id_miss, sizeof(int) * (size_t)d->n_nodes);
+    f.add(d->leaf_first, sizeof(int) * (size_t)d->n_nodes); f.add(d->leaf_count, sizeof(int) * (size_t)d->n_nodes);
+    f.add(d->tri_index, sizeof(int) * (size_t)d->n_tri_index);
+    f.add(d->pos, sizeof(float) * 9 * (size_t)d->n_tris);
+    for (int i = 0; i < d->n_lights; i++) f.add(d->lights[i].position, sizeof d->lights[i].position);
+    return f.h;
+}
+struct WideCacheHeader {
+    char magic[8];
+    unsigned version, wideOk;
+    unsigned long long key;
+    int nWide;
+    float wideInvScale;
+    unsigned long long nWnodes, nLeafBox, nLeafHead, payloadHash;
+};
+bool load_wide_cache(const char* path, unsigned long long key, mipt_scene* s) {
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return false;
+    WideCacheHeader h{};
+    bool ok = fread(&h, sizeof h, 1, fp) == 1 && memcmp(h.magic, "MIPTWIDE", 8) == 0 && h.version == kWideCacheVersion && h.key == key &&
+              h.nWnodes < (1ull << 28) && h.nLeafBox < (1ull << 28) && h.nLeafHead < (1ull << 28);
+    std::vector<float4> wn, lb, lh;
+    if (ok) {
+        wn.resize((size_t)h.nWnodes); lb.resize((size_t)h.nLeafBox); lh.resize((size_t)h.nLeafHead);
+        ok = (wn.empty() || fread(wn.data(), sizeof(float4), wn.size(), fp) == wn.size()) &&
+             (lb.empty() || fread(lb.data(), sizeof(float4), lb.size(), fp) == lb.size()) &&
+             (lh.empty() || fread(lh.data(), sizeof(float4), lh.size(), fp) == lh.size()) && fgetc(fp) == EOF;
+    }
+    fclose(fp);
+    if (!ok) return false;
+    Fnv f;
+    f.add(wn.data(), wn.size() * sizeof(float4)); f.add(lb.data(), lb.size() * sizeof(float4)); f.add(lh.data(), lh.size() * sizeof(float4));
+    if (f.h != h.payloadHash) return false;
+    if (h.wideOk && (h.nWide <= 0 || wn.size() != (size_t)ptd::kWideNodeStrideF4 * (size_t)h.nWide)) return false;
+    s->wnodes.swap(wn); s->leafBox.swap(lb); s->leafHead.swap(lh);
+    s->nWide = h.nWide; s->wideInvScale = h.wideInvScale; s->wideOk = h.wideOk != 0;
+    return true;
+}
+void save_wide_cache(const char* path, unsigned long long key, const mipt_scene* s) {
+    WideCacheHeader h{};
+    memcpy(h.magic, "MIPTWIDE", 8);
+    h.version = kWideCacheVersion; h.wideOk = s->wideOk ? 1u : 0u; h.key = key; h.nWide = s->nWide; h.wideInvScale = s->wideInvScale;
+    h.nWnodes = s->wnodes.size(); h.nLeafBox = s->leafBox.size(); h.nLeafHead = s->leafHead.size();
+    Fnv f;
+    f.add(s->wnodes.data(), s->wnodes.size() * sizeof(float4)); f.add(s->leafBox.data(), s->leafBox.size() * sizeof(float4));
+    f.add(s->leafHead.data(), s->leafHead.size() * sizeof(float4));
+    h.payloadHash = f.h;
+    const std::string tmp = std::string(path) + ".tmp" + std::to_string((unsigned long long)(uintptr_t)s);
+    FILE* fp = fopen(tmp.c_str(), "wb");
+    if (!fp) return;  // a cache that cannot be written is not an error of scene creation
+    const bool ok = fwrite(&h, sizeof h, 1, fp) == 1 &&
+                    (s->wnodes.empty() || fwrite(s->wnodes.data(), sizeof(float4), s->wnodes.size(), fp) == s->wnodes.size()) &&
+                    (s->leafBox.empty() || fwrite(s->leafBox.data(), sizeof(float4), s->leafBox.size(), fp) == s->leafBox.size()) &&
+                    (s->leafHead.empty() || fwrite(s->leafHead.data(), sizeof(float4), s->leafHead.size(), fp) == s->leafHead.size());
+    if (fclose(fp) != 0 || !ok || rename(tmp.c_str(), path) != 0) (void)remove(tmp.c_str());
+}
+
+int scene_create_impl(const mipt_scene_desc* d, const char* wide_cache_path, mipt_scene** out);
+
 }  // namespace
 
 extern "C" {
 
-int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
+int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) { return scene_create_impl(d, nullptr, out); }
+int mipt_scene_create_cached(const mipt_scene_desc* d, const char* wide_cache_path, mipt_scene** out) {
+    return scene_create_impl(d, (wide_cache_path && *wide_cache_path) ? wide_cache_path : nullptr, out);
+}
+
+}  // extern "C"
+
+namespace {
+
+int scene_create_impl(const mipt_scene_desc* d, const char* wide_cache_path, mipt_scene** out) {
     if (!d || !out) return fail(MIPT_ERR_INVALID, "mipt_scene_create: null argument");
     if (d->n_nodes <= 0 || d->n_tris <= 0 || d->n_tri_index <= 0 || !d->node_min || !d->node_max || !d->id_hit ||
         !d->id_miss || !d->leaf_first || !d->leaf_count || !d->tri_index || !d->pos || !d->nrm || !d->uv || !d->mat_id)
@@ -1005,9 +1280,13 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
         // the best tree first; the only way one fails is by being deeper than the kernel's stacks, then the next best is
         // tried, down to the plain grandchildren of the reference's tree
         s->wideOk = false;
-        for (int m = mode; m >= 0 && !s->wideOk; m--)
-            for (int t = (m > 0 ? top : 0); t >= 0 && !s->wideOk; t--) s->wideOk = build_wide(d, s, m, t);
-        if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear(); s->nWide = 0; }
+        const unsigned long long key = wide_cache_path ? wide_key(d, mode, top) : 0ull;
+        if (!(wide_cache_path && load_wide_cache(wide_cache_path, key, s))) {
+            for (int m = mode; m >= 0 && !s->wideOk; m--)
+                for (int t = (m > 0 ? top : 0); t >= 0 && !s->wideOk; t--) s->wideOk = build_wide(d, s, m, t);
+            if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear(); s->nWide = 0; }
+            if (wide_cache_path) save_wide_cache(wide_cache_path, key, s);
+        }
         if (is_binary_tree(d)) {  // right child = where the left subtree's walk exits; independent of the wide tree and of the planes
             s->nodeRight.assign((size_t)n, 0);
             s->btLinks.assign((size_t)n, make_int4(0, 0, 0, 0));  // root: idParent = idSibling = 0, C:1716-1717
@@ -1073,9 +1352,21 @@ int mipt_scene_create(const mipt_scene_desc* d, mipt_scene** out) {
     });
 }
 
+}  // namespace
+
+extern "C" {
+
 void mipt_scene_destroy(mipt_scene* s) { delete s; }
 int mipt_scene_exact_reciprocal(const mipt_scene* s) { return (s && s->planesTame) ? 1 : 0; }
 int mipt_scene_wide_nodes(const mipt_scene* s) { return (s && s->wideOk) ? s->nWide : 0; }
+uint64_t mipt_scene_wide_hash(const mipt_scene* s) {
+    if (!s) return 0;
+    Fnv f;
+    f.pod(s->nWide); f.pod(s->wideInvScale);
+    f.add(s->wnodes.data(), s->wnodes.size() * sizeof(float4)); f.add(s->leafBox.data(), s->leafBox.size() * sizeof(float4));
+    f.add(s->leafHead.data(), s->leafHead.size() * sizeof(float4));
+    return f.h;
+}
 
 // What the order-free traversal rests on, checked on the finished arrays (host only, no GPU): the wide tree reaches
 // every leaf of the scene exactly once, every slot's STORED box (fp16, rounded outwards) contains the stored boxes of

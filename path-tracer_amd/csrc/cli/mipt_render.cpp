@@ -11,7 +11,8 @@
 //               [--gpus N]               the frame's tiles over GPUs 0..N-1, gathered to GPU 0 with one RCCL collective
 //                                        (mipt_node_*); the image is bit-identical to the one-GPU image
 //               [--cache scene.miptsc]   mesh + BVH from this flat file when it exists and loads, else parsed and
-//                                        built as usual and then written to it (mipt_scene_cache_*)
+//                                        built as usual and then written to it (mipt_scene_cache_*); the hierarchy
+//                                        the traversal walks is kept beside it (<file>.wide, mipt_scene_create_cached)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -116,7 +117,15 @@ int main(int argc, char** argv) {
     mipt_scene_desc desc;
     if (mipt_scene_desc_fill(mesh, bvh, env, &light, 1, &desc) != MIPT_OK) die("scene description");
     mipt_scene* scene = nullptr;
-    if (mipt_scene_create(&desc, &scene) != MIPT_OK) die("scene");
+    {
+        // with --cache the library's own hierarchy above the leaves lives beside the flat scene file (<cache>.wide, keyed on
+        // the tree, the leaf order, the positions and the light: mipt_scene_create_cached), so a second start builds nothing
+        const auto t0 = std::chrono::steady_clock::now();
+        const std::string widePath = cachePath.empty() ? std::string() : cachePath + ".wide";
+        if (mipt_scene_create_cached(&desc, widePath.c_str(), &scene) != MIPT_OK) die("scene");
+        printf("Scene ready in %.1f ms (%d wide nodes%s).\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+               mipt_scene_wide_nodes(scene), widePath.empty() ? "" : ", hierarchy cache beside the scene cache");
+    }
     if (cam.width <= 0 || cam.height <= 0 || cam.width > 32768 || cam.height > 32768) {
         fprintf(stderr, "mipt_render: --width / --height must be in 1..32768\n");
         return 2;

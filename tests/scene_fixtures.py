@@ -50,12 +50,13 @@ def oracle_scene_from_mesh_arrays(pos, nrm, uv, mid, mats, texs, env=None, light
     return ob.OracleScene(pos, nrm, uv, mid, mats, texs, env=env, lights=lights)
 
 
-def product_scene_from_mesh_arrays(pos, nrm, uv, mid, mats, texs, env=None, lights=DEFAULT_LIGHT, all_axes=False):
-    """all_axes: the three-axis SAH build (mipt_bvh_build_all_axes) instead of the reference's tree"""
+def product_scene_from_mesh_arrays(pos, nrm, uv, mid, mats, texs, env=None, lights=DEFAULT_LIGHT, all_axes=False, wide_cache=None):
+    """all_axes: the three-axis SAH build (mipt_bvh_build_all_axes) instead of the reference's tree;
+    wide_cache: file that keeps the library's hierarchy above the leaves (mipt_scene_create_cached)"""
     B = importlib.import_module("path-tracer_amd.binding")
     mesh = B.Mesh.from_arrays(pos, nrm, uv, mid, mats, texs)
     img = B.Image.from_array(env) if env is not None else None
-    return B.Scene(mesh, bvh=B.BVH(mesh, all_axes=True) if all_axes else None, env=img, lights=lights)
+    return B.Scene(mesh, bvh=B.BVH(mesh, all_axes=True) if all_axes else None, env=img, lights=lights, wide_cache=wide_cache)
 
 
 def procedural_env(size=256):

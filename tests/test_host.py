@@ -394,3 +394,41 @@ def test_wide_tree_over_the_references_leaves(B, sf, name, top, monkeypatch):
     assert leaves > 0 and 0 <= depth < 16
     if n_leaves_ref is not None:
         assert leaves == n_leaves_ref
+
+
+def test_wide_hierarchy_cache_and_thread_independence(B, sf, tmp_path, monkeypatch):
+    """mipt_scene_create_cached: the second creation loads the hierarchy the first one built -- the same arrays bit for bit
+    (mipt_scene_wide_hash) and faster; a build on one thread and on all of them give the same tree; a damaged or foreign
+    file is ignored and rewritten; other lights (the slot order depends on them) are another key"""
+    import time
+    arrays = sf.sponza_standin(1)
+    path = str(tmp_path / "atrium.wide")
+    t0 = time.perf_counter()
+    a = sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT, wide_cache=path)
+    t_build = time.perf_counter() - t0
+    assert os.path.getsize(path) > 1000 and a.wide_nodes > 0
+    a.selfcheck_wide()
+    t0 = time.perf_counter()
+    b = sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT, wide_cache=path)
+    t_load = time.perf_counter() - t0
+    assert b.wide_hash == a.wide_hash and b.wide_nodes == a.wide_nodes
+    b.selfcheck_wide()
+    assert t_load < t_build  # (the mesh upload and the reference BVH are in both)
+    plain = sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT)
+    assert plain.wide_hash == a.wide_hash
+    monkeypatch.setenv("MIPT_BUILD_THREADS", "1")
+    one = sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT)
+    monkeypatch.setenv("MIPT_BUILD_THREADS", "5")
+    five = sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT)
+    monkeypatch.delenv("MIPT_BUILD_THREADS")
+    assert one.wide_hash == a.wide_hash and five.wide_hash == a.wide_hash
+    # damage: a flipped byte in the payload, a truncated file, a foreign file -> rebuilt, same tree, file whole again
+    good = open(path, "rb").read()
+    for bad in (good[:200] + bytes([good[200] ^ 1]) + good[201:], good[: len(good) // 2], b"not a cache"):
+        open(path, "wb").write(bad)
+        c = sf.product_scene_from_mesh_arrays(*arrays, lights=sf.SPONZA_LIGHT, wide_cache=path)
+        assert c.wide_hash == a.wide_hash
+        assert open(path, "rb").read() == good
+    other = sf.product_scene_from_mesh_arrays(*arrays, lights=((0.0, 1.0, 0.0, 10.0, 10.0, 10.0),), wide_cache=path)
+    assert other.wide_nodes > 0 and open(path, "rb").read() != good  # another key: rebuilt and overwritten
+    other.selfcheck_wide()
