@@ -194,7 +194,14 @@ def main():
     if len(sys.argv) == 6 and sys.argv[1] == "--cpu-rows":  # a worker of cpu_baseline_all_cores: no torch, no GPU
         print(json.dumps(_cpu_worker((int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])))), flush=True)
         return 0
+    if len(sys.argv) >= 3 and sys.argv[1] == "--native-node-child":  # a process of its own: the native one-process node
+        return native_node_child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     ap = argparse.ArgumentParser()
+    ap.add_argument("--native-node", action="store_true",
+                    help="after the headline measurement, rank 0 also times the NATIVE node (mipt_node_render: one process, a host "
+                         "thread + stream + context per GPU, RCCL gather of the owned tiles) on the same N GPUs and the same frame, "
+                         "in a child process under a time limit; reported as config.native_node (on by default for N > 1)")
+    ap.add_argument("--no-native-node", action="store_true")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -362,6 +369,16 @@ def main():
         weak = {"value": w_rays / w_max / 1e6, "unit": "Mrays/s", "ms_per_step": w_max / args.steps * 1e3,
                 "spp_per_step": args.spp * world, "scaling": "weak"}
 
+    native = None
+    if (args.native_node or world > 1) and not args.no_native_node:
+        # the other ranks keep their contexts but are idle (they wait at the barrier below) while rank 0's child runs
+        torch.cuda.synchronize(dev)
+        if multi:
+            dist.barrier()
+        if rank == 0:
+            native = time_native_node(world, args.steps, args.warmup, args.detail)
+        if multi:
+            dist.barrier()
     if rank == 0:
         def kernel_line(rays_k, visits, tests, ms, launches):
             byts = algorithmic_bytes(rays_k, visits, tests)
@@ -431,7 +448,7 @@ def main():
                        "rays_per_step": total_rays / args.steps, "ms_per_frame_1spp": ms_frame,
                        "scene_create_s": t_scene,
                        "ms_per_step_serialised_with_events": serial_elapsed / args.steps * 1e3,
-                       "weak_scaling": weak},
+                       "weak_scaling": weak, "native_node": native},
             "roofline": {"bound": "valu", "achieved": dom_ref["achieved_TFLOPs"], "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom_ref["achieved_TFLOPs"] / FP32_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": dom_name,
                          "flops_per_ray_reference_walk": dom_ref["algorithmic_flops_per_ray"],
@@ -503,6 +520,45 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def native_node_child(ngpus, steps, warmup, detail):
+    """the same frame through mipt_node_* (api/api_node.hip): one process, ngpus GPUs; prints one JSON line"""
+    import scene_fixtures as sf
+    B = importlib.import_module("path-tracer_amd").binding
+    scene = sf.product_scene_from_mesh_arrays(*sf.sponza_standin(detail), env=sf.procedural_env(1024), lights=sf.SPONZA_LIGHT)
+    node = B.Node(scene, ngpus=ngpus)
+    cam = B.make_camera(W, H, sf.SPONZA_EYE, sf.SPONZA_LOOKAT)
+    for _ in range(warmup):
+        node.render(cam, mode=B.MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, tile_w=TILE_W, tile_h=TILE_H, readback=False)
+    node.synchronize()
+    r0 = node.stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):  # one fresh 16-spp frame per step, gathered on GPU 0, nothing copied to the host
+        node.render(cam, mode=B.MODE_PATH, spp=SPP, max_bounces=BOUNCES, seed=SEED, tile_w=TILE_W, tile_h=TILE_H, readback=False)
+    node.synchronize()
+    dt = time.perf_counter() - t0
+    r1 = node.stats()
+    rays = (r1["rays_closest"] + r1["rays_occluded"]) - (r0["rays_closest"] + r0["rays_occluded"])
+    print(json.dumps({"value": rays / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / steps * 1e3, "n_gpus": ngpus, "steps": steps,
+                      "uses_rccl": node.uses_rccl, "scaling": "strong",
+                      "what": "mipt_node_render: one process, a host thread + stream + context per GPU, owned tiles gathered to GPU 0 "
+                              "over RCCL (grouped send / receive of exactly the owned bytes), frame left on GPU 0"}), flush=True)
+    return 0
+
+
+def time_native_node(ngpus, steps, warmup, detail, limit=240.0):
+    """runs native_node_child in a process of its own (a fault or a hang there must not take the headline with it)"""
+    try:
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--native-node-child", str(ngpus), str(steps), str(warmup), str(detail)],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit)
+        if pr.returncode != 0:
+            return {"error": f"child exited with status {pr.returncode}: {pr.stderr.strip().splitlines()[-1] if pr.stderr.strip() else ''}"}
+        return json.loads(pr.stdout.strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"child still running after {limit:.0f} s; killed"}
+    except Exception as e:
+        return {"error": str(e)}
 
 
 def dry_run(args, rank, world, torch, dist, pkg):

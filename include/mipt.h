@@ -351,9 +351,15 @@ int mipt_node_uses_rccl(const mipt_node*);
 /* Scene::Raytrace / Scene::Pathtrace (C:2200-2261) of the whole frame; params->part_index / part_count are ignored.
  * Path mode is progressive across calls as in mipt_render_device: a call with sample_offset > 0 continues the
  * accumulation of the previous calls (same camera and resolution), sample_offset == 0 starts a new frame.
- * rgb_host: width*height*3 floats on the HOST, or NULL to leave the frame on GPU 0 (timing runs).  Returns after the
- * frame is complete on GPU 0 (and copied, if asked). */
+ * rgb_host: width*height*3 floats on the HOST: the call returns when the frame is complete and copied.  NULL: the frame
+ * stays on GPU 0 and the call returns with its work ENQUEUED (round 3): the gather of this call runs on a transfer stream
+ * per GPU beside the kernels of the next call (two send slots used in turn), which is what a progressive sequence --
+ * many calls, the frame fetched by the last one -- wants; mipt_node_synchronize waits for everything enqueued.
+ * The gather moves exactly the owned tiles, point to point (grouped ncclSend / ncclRecv; rank 0's own tiles stay where
+ * they are), or, with MIPT_NODE_GATHER=gather, one ncclGather over equal slots. */
 int mipt_node_render(mipt_node*, const mipt_camera* cam, const mipt_render_params* params, float* rgb_host);
+/* waits until every GPU of the node has finished what mipt_node_render enqueued */
+int mipt_node_synchronize(mipt_node*);
 /* sum of the per-GPU statistics (mipt_context_get_stats); last_frame_ms (may be NULL): host wall time of the last
  * mipt_node_render call */
 int mipt_node_get_stats(mipt_node*, mipt_stats* out, double* last_frame_ms);

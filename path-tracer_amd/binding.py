@@ -85,7 +85,7 @@ SYMBOLS = [
     "mipt_selftest_fast_division", "mipt_selftest_vec_ops", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
     "mipt_render_device", "mipt_render", "mipt_context_synchronize", "mipt_context_set_profiling",
     "mipt_context_set_counting", "mipt_context_set_overlap", "mipt_context_get_stats", "mipt_context_reset_stats", "mipt_context_set_traversal",
-    "mipt_node_create", "mipt_node_destroy", "mipt_node_num_gpus", "mipt_node_uses_rccl", "mipt_node_render",
+    "mipt_node_create", "mipt_node_destroy", "mipt_node_num_gpus", "mipt_node_uses_rccl", "mipt_node_render", "mipt_node_synchronize",
     "mipt_node_get_stats", "mipt_render_node",
 ]
 
@@ -192,6 +192,7 @@ def lib():
     L.mipt_node_num_gpus.argtypes = [vp]
     L.mipt_node_uses_rccl.argtypes = [vp]
     L.mipt_node_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), fp]
+    L.mipt_node_synchronize.argtypes = [vp]
     L.mipt_node_get_stats.argtypes = [vp, C.POINTER(Stats), C.POINTER(C.c_double)]
     L.mipt_render_node.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), C.c_int, fp]
     _lib = L
@@ -673,6 +674,10 @@ class Node:
         rgb = np.zeros((cam.height, cam.width, 3), np.float32) if readback else None
         check(lib().mipt_node_render(self.h, C.byref(cam), C.byref(p), _fp(rgb)))
         return rgb
+
+    def synchronize(self):
+        """waits for what render(readback=False) left enqueued"""
+        check(lib().mipt_node_synchronize(self.h))
 
     def stats(self):
         s, ms = Stats(), C.c_double()

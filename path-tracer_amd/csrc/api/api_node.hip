@@ -35,6 +35,7 @@ struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional: ends a collective that a failed rank never joined
     ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;  // an RCCL extension: may be absent
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -60,13 +61,14 @@ const Rccl* load_rccl() {
     r.handle = h;
     r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
     r.Gather = (decltype(r.Gather))dlsym(h, "ncclGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
     r.Recv = (decltype(r.Recv))dlsym(h, "ncclRecv");
     r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
-    if (getenv("MIPT_NODE_NO_NCCLGATHER")) r.Gather = nullptr;  // tests: take the grouped send / receive path
+    if (getenv("MIPT_NODE_NO_NCCLGATHER")) r.Gather = nullptr;  // tests: the grouped send / receive path also for one GPU
     const bool p2p = r.Send && r.Recv && r.GroupStart && r.GroupEnd;
     if (!r.CommInitAll || !r.CommDestroy || !r.GetErrorString || (!r.Gather && !p2p)) {
         g_rccl.error = "RCCL lacks ncclCommInitAll / ncclCommDestroy / ncclGetErrorString, or both ncclGather and ncclSend / ncclRecv";
@@ -84,9 +86,14 @@ struct Rank {
     hipStream_t stream = nullptr;
     mipt_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
+    hipStream_t xfer = nullptr;   // the gather runs here, beside the next frame's kernels on `stream`
     hipEvent_t packed = nullptr;  // same-GPU gather: this rank's tiles have arrived in rank 0's receive buffer
+    hipEvent_t evPacked = nullptr;    // `stream`: this frame's tiles are in its send slot (and the frame itself is complete)
+    hipEvent_t evSent[2] = {nullptr, nullptr};  // `xfer`: the transfer out of send slot k has finished
+    hipEvent_t evDone = nullptr;      // `xfer`: everything of this frame is done (rank 0: the other ranks' tiles are in its frame)
+    unsigned long long frameNo = 0;   // frames rendered with this layout: send slot = frameNo & 1
     // frame state, (re)allocated when the resolution or the tiling changes
-    void* frameMem = nullptr;     // accum | rgb | send | (rank 0) recv | tile lists
+    void* frameMem = nullptr;     // accum | rgb | send x 2 | (rank 0) recv | tile lists
     float *accum = nullptr, *rgb = nullptr, *send = nullptr, *recv = nullptr;
     int* tiles = nullptr;         // this rank's owned tile ids; rank 0: every rank's list, rank r's at tileOfs[r]
     unsigned nTiles = 0;
@@ -113,6 +120,9 @@ struct mipt_node {
     size_t maxTiles = 0, slotFloats = 0;   // floats per rank in the gather (maxTiles x tile pixels x 3)
     unsigned long long layoutGen = 0;      // bumped whenever the above changes
     std::atomic<int> failed{0};            // a rank failed before the gather: nobody enters it
+    std::atomic<int> failedGather{0};      // a rank failed to enqueue its part of the gather: nobody waits for it
+    bool exact = false;                    // RCCL: grouped send / receive of exactly the owned tiles instead of ncclGather
+                                           // over maxTiles-sized slots (rank 0 keeps its own tiles where they are)
     // job hand-over
     std::mutex m;
     std::condition_variable cvGo, cvDone;
@@ -123,6 +133,8 @@ struct mipt_node {
     mipt_render_params rp{};
     float* rgbHost = nullptr;
     bool clear = false;
+    bool async = true;   // a call without a host buffer returns with its work enqueued (MIPT_NODE_ASYNC=0: always wait)
+    bool dead = false;   // a failed gather aborted the communicator
     double lastMs = 0.0;
 };
 
@@ -163,22 +175,30 @@ int ensure_frame(mipt_node* nd, int ri) {
     size_t nList = nd->owned[(size_t)ri].size();
     if (ri == 0) { nList = 0; for (const auto& o : nd->owned) nList += o.size(); }
     const size_t listBytes = align256(nList * sizeof(int) + 4);
-    if (r.frameMem) { NODE_HIP(hipStreamSynchronize(r.stream)); NODE_HIP(hipFree(r.frameMem)); r.frameMem = nullptr; }
-    NODE_HIP(hipMalloc(&r.frameMem, 2 * frameBytes + sendBytes + recvBytes + listBytes));
+    NODE_HIP(hipStreamSynchronize(r.stream));
+    NODE_HIP(hipStreamSynchronize(r.xfer));
+    if (r.frameMem) { NODE_HIP(hipFree(r.frameMem)); r.frameMem = nullptr; }
+    NODE_HIP(hipMalloc(&r.frameMem, 2 * frameBytes + 2 * sendBytes + recvBytes + listBytes));
     unsigned char* b = (unsigned char*)r.frameMem;
-    r.accum = (float*)b; r.rgb = (float*)(b + frameBytes); r.send = (float*)(b + 2 * frameBytes);
-    r.recv = ri == 0 ? (float*)(b + 2 * frameBytes + sendBytes) : nullptr;
-    r.tiles = (int*)(b + 2 * frameBytes + sendBytes + recvBytes);
+    r.accum = (float*)b; r.rgb = (float*)(b + frameBytes); r.send = (float*)(b + 2 * frameBytes);  // slot k at send + k * slotStride
+    r.recv = ri == 0 ? (float*)(b + 2 * frameBytes + 2 * sendBytes) : nullptr;
+    r.tiles = (int*)(b + 2 * frameBytes + 2 * sendBytes + recvBytes);
+    r.frameNo = 0;
     std::vector<int> list;
     if (ri == 0) for (const auto& o : nd->owned) list.insert(list.end(), o.begin(), o.end());
     else list = nd->owned[(size_t)ri];
     if (!list.empty()) NODE_HIP(hipMemcpy(r.tiles, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice));
-    NODE_HIP(hipMemsetAsync(r.frameMem, 0, 2 * frameBytes + sendBytes + recvBytes, r.stream));
+    NODE_HIP(hipMemsetAsync(r.frameMem, 0, 2 * frameBytes + 2 * sendBytes + recvBytes, r.stream));
+    NODE_HIP(hipStreamSynchronize(r.stream));  // (the receive buffer is written from other streams: zeroed before anyone can)
     r.nTiles = (unsigned)nd->owned[(size_t)ri].size();
     return MIPT_OK;
 }
 
-// phase A: everything up to and including this rank's packed tiles, enqueued on its stream
+// floats of rank k's owned tiles
+size_t owned_floats(const mipt_node* nd, int k) { return nd->owned[(size_t)k].size() * (size_t)nd->tileW * nd->tileH * 3; }
+float* send_slot(const mipt_node* nd, const Rank& r) { return r.send + (r.frameNo & 1ull) * (align256(nd->slotFloats * sizeof(float)) / sizeof(float)); }
+
+// phase A: everything up to and including this rank's packed tiles, enqueued on its render stream
 int render_rank_enqueue(mipt_node* nd, int ri) {
     Rank& r = nd->ranks[(size_t)ri];
     NODE_HIP(hipSetDevice(r.device));
@@ -187,6 +207,8 @@ int render_rank_enqueue(mipt_node* nd, int ri) {
         if (rc != MIPT_OK) return rc;
         r.layoutSeen = nd->layoutGen;
     } else if (nd->clear) {
+        // a fresh frame: the previous one's transfer (rank 0: the unpack into this very buffer) must be over first
+        NODE_HIP(hipStreamWaitEvent(r.stream, r.evDone, 0));
         const size_t frameBytes = align256((size_t)3 * nd->cam.width * nd->cam.height * sizeof(float));
         NODE_HIP(hipMemsetAsync(r.frameMem, 0, 2 * frameBytes, r.stream));  // AccumulationBuffer.clear(), sampleCount = 0
     }
@@ -194,66 +216,96 @@ int render_rank_enqueue(mipt_node* nd, int ri) {
     rp.part_index = ri; rp.part_count = nd->n; rp.tile_w = nd->tileW; rp.tile_h = nd->tileH;
     const int rc = mipt_render_device(r.ctx, &nd->cam, &rp, r.accum, r.rgb);
     if (rc != MIPT_OK) { r.error = mipt_last_error(); return rc; }
-    if (nd->useRccl || (nd->n > 1 && ri != 0))  // rank 0's own tiles are already in its frame; ncclGather wants its share too
+    const bool sends = nd->useRccl ? (!nd->exact || ri != 0 || nd->n == 1) : (nd->n > 1 && ri != 0);  // rank 0's own tiles are already in its frame
+    if (sends) {
+        // the send slots are used in turn: the transfer that read this one two frames ago must be over
+        NODE_HIP(hipStreamWaitEvent(r.stream, r.evSent[r.frameNo & 1ull], 0));
         ptd::launch_pack_tiles(r.stream, r.rgb, ri == 0 ? r.tiles + nd->tileOfs[0] : r.tiles, r.nTiles, nd->tileW, nd->tileH,
-                               nd->tilesX, nd->cam.width, nd->cam.height, r.send);
+                               nd->tilesX, nd->cam.width, nd->cam.height, send_slot(nd, r));
+    }
     NODE_HIP(hipGetLastError());
+    NODE_HIP(hipEventRecord(r.evPacked, r.stream));
     return MIPT_OK;
 }
-// phase B: the gather to rank 0, rank 0's unpack and readback.  Entered only when EVERY rank came through phase A (a
-// collective that one rank never joins would leave the others' streams waiting for ever).
-int render_rank_gather(mipt_node* nd, int ri) {
+// phase B: the gather to rank 0 and rank 0's unpack, enqueued on the TRANSFER stream behind evPacked, so that the next
+// frame's kernels (render stream) run beside them.  Entered only when EVERY rank came through phase A (a collective that
+// one rank never joins would leave the others' streams waiting for ever).
+int render_rank_gather_enqueue(mipt_node* nd, int ri) {
     Rank& r = nd->ranks[(size_t)ri];
+    NODE_HIP(hipStreamWaitEvent(r.xfer, r.evPacked, 0));
     if (nd->n > 1 || nd->useRccl) {
+        float* const slot = send_slot(nd, r);
         if (nd->useRccl) {
             ncclResult_t e;
-            if (nd->rccl->Gather) {
-                e = nd->rccl->Gather(r.send, r.recv, nd->slotFloats, ncclFloat, 0, r.comm, r.stream);
-            } else {  // the same exchange as one group of point-to-point operations: every rank sends, rank 0 receives N
+            if (!nd->exact) {
+                e = nd->rccl->Gather(slot, r.recv, nd->slotFloats, ncclFloat, 0, r.comm, r.xfer);
+            } else {
+                // one group of point-to-point operations with exactly the owned bytes: every rank but 0 sends, rank 0
+                // receives N - 1 (a one-GPU node sends to itself, so that the same calls run on every N)
                 e = nd->rccl->GroupStart();
-                if (e == ncclSuccess) e = nd->rccl->Send(r.send, nd->slotFloats, ncclFloat, 0, r.comm, r.stream);
-                for (int k = 0; ri == 0 && k < nd->n && e == ncclSuccess; k++)
-                    e = nd->rccl->Recv(r.recv + (size_t)k * nd->slotFloats, nd->slotFloats, ncclFloat, k, r.comm, r.stream);
+                if (e == ncclSuccess && (ri != 0 || nd->n == 1)) e = nd->rccl->Send(slot, owned_floats(nd, ri), ncclFloat, 0, r.comm, r.xfer);
+                for (int k = nd->n == 1 ? 0 : 1; ri == 0 && k < nd->n && e == ncclSuccess; k++)
+                    e = nd->rccl->Recv(r.recv + (size_t)k * nd->slotFloats, owned_floats(nd, k), ncclFloat, k, r.comm, r.xfer);
                 const ncclResult_t e2 = nd->rccl->GroupEnd();
                 if (e == ncclSuccess) e = e2;
             }
             if (e != ncclSuccess) { r.error = std::string("RCCL gather failed: ") + nd->rccl->GetErrorString(e); return MIPT_ERR_DEVICE; }
-        } else {  // ranks share a GPU: a device-to-device copy into rank 0's slot, ordered by an event
-            hipError_t ce = hipSuccess;
-            if (ri != 0) {
-                ce = hipMemcpyAsync(nd->ranks[0].recv + (size_t)ri * nd->slotFloats, r.send, nd->slotFloats * sizeof(float),
-                                    hipMemcpyDeviceToDevice, r.stream);
-                if (ce == hipSuccess) ce = hipEventRecord(r.packed, r.stream);
-            }
-            rank_barrier(nd);  // every event is recorded (a rank that failed still comes here: nobody waits for ever)
-            NODE_HIP(ce);
-            if (ri == 0)
-                for (int k = 1; k < nd->n; k++) NODE_HIP(hipStreamWaitEvent(r.stream, nd->ranks[(size_t)k].packed, 0));
+        } else if (ri != 0) {  // ranks share a GPU: a device-to-device copy into rank 0's slot once rank 0 is done with the last frame's
+            NODE_HIP(hipStreamWaitEvent(r.xfer, nd->ranks[0].evDone, 0));
+            NODE_HIP(hipMemcpyAsync(nd->ranks[0].recv + (size_t)ri * nd->slotFloats, slot, owned_floats(nd, ri) * sizeof(float),
+                                    hipMemcpyDeviceToDevice, r.xfer));
+            NODE_HIP(hipEventRecord(r.packed, r.xfer));
         }
-        if (ri == 0)
-            for (int k = 1; k < nd->n; k++)
-                ptd::launch_unpack_tiles(r.stream, r.recv + (size_t)k * nd->slotFloats, r.tiles + nd->tileOfs[(size_t)k],
-                                         (unsigned)nd->owned[(size_t)k].size(), nd->tileW, nd->tileH, nd->tilesX, nd->cam.width,
-                                         nd->cam.height, r.rgb);
+    }
+    NODE_HIP(hipEventRecord(r.evSent[r.frameNo & 1ull], r.xfer));
+    return MIPT_OK;
+}
+// phase C (after a host barrier: every rank's `packed` event is recorded): rank 0 unpacks; everyone marks the frame done
+int render_rank_finish(mipt_node* nd, int ri, bool waitForIt) {
+    Rank& r = nd->ranks[(size_t)ri];
+    if (ri == 0 && nd->n > 1) {
+        if (!nd->useRccl)
+            for (int k = 1; k < nd->n; k++) NODE_HIP(hipStreamWaitEvent(r.xfer, nd->ranks[(size_t)k].packed, 0));
+        for (int k = 1; k < nd->n; k++)
+            ptd::launch_unpack_tiles(r.xfer, r.recv + (size_t)k * nd->slotFloats, r.tiles + nd->tileOfs[(size_t)k],
+                                     (unsigned)nd->owned[(size_t)k].size(), nd->tileW, nd->tileH, nd->tilesX, nd->cam.width,
+                                     nd->cam.height, r.rgb);
         NODE_HIP(hipGetLastError());
     }
     if (ri == 0 && nd->rgbHost)
-        NODE_HIP(hipMemcpyAsync(nd->rgbHost, r.rgb, (size_t)3 * nd->cam.width * nd->cam.height * sizeof(float), hipMemcpyDeviceToHost, r.stream));
-    NODE_HIP(hipStreamSynchronize(r.stream));
+        NODE_HIP(hipMemcpyAsync(nd->rgbHost, r.rgb, (size_t)3 * nd->cam.width * nd->cam.height * sizeof(float), hipMemcpyDeviceToHost, r.xfer));
+    NODE_HIP(hipEventRecord(r.evDone, r.xfer));
+    r.frameNo++;
+    if (waitForIt) {
+        NODE_HIP(hipStreamSynchronize(r.xfer));
+        NODE_HIP(hipStreamSynchronize(r.stream));
+    }
     return MIPT_OK;
 }
 int render_rank(mipt_node* nd, int ri) {
     Rank& r = nd->ranks[(size_t)ri];
     int rc = render_rank_enqueue(nd, ri);
     if (rc != MIPT_OK) nd->failed.store(1);
-    rank_barrier(nd);  // every rank has enqueued its frame (or failed); same-GPU ranks have recorded their events
+    rank_barrier(nd);  // every rank has enqueued its frame (or failed)
     if (nd->failed.load()) {
         (void)hipStreamSynchronize(r.stream);
         if (rc == MIPT_OK) { rc = MIPT_ERR_DEVICE; r.error = "another rank failed before the gather"; }
         return rc;
     }
-    rc = render_rank_gather(nd, ri);
-    if (!nd->useRccl && nd->n > 1) rank_barrier(nd);  // rank 0 has consumed its receive buffer before anyone packs into it again
+    rc = render_rank_gather_enqueue(nd, ri);
+    if (rc != MIPT_OK) nd->failedGather.store(1);
+    rank_barrier(nd);  // every rank has enqueued its part of the gather (or failed to); same-GPU ranks have recorded their events
+    if (nd->failedGather.load()) {
+        // the collective is short of a rank: nobody waits for it.  Where RCCL offers it the communicator is aborted, which
+        // ends the operations already enqueued; the node is unusable afterwards and says so.
+        if (nd->useRccl && nd->rccl->CommAbort && r.comm) { (void)nd->rccl->CommAbort(r.comm); r.comm = nullptr; }
+        if (rc == MIPT_OK) { rc = MIPT_ERR_DEVICE; r.error = "another rank failed to enqueue its part of the gather"; }
+        return rc;
+    }
+    // a caller that passed a host buffer gets the finished frame; one that did not (progressive accumulation, the frame
+    // fetched by a later call) gets control back with the work enqueued
+    rc = render_rank_finish(nd, ri, nd->rgbHost != nullptr || !nd->async);
+    if (!nd->useRccl && nd->n > 1) rank_barrier(nd);  // rank 0's evDone is recorded before anyone enqueues a copy behind it
     return rc;
 }
 
@@ -296,6 +348,11 @@ int mipt_node_create(const mipt_scene* scene, int ngpus, const int* devices, mip
     if (!scene || !out || ngpus <= 0 || ngpus > 64) return fail(MIPT_ERR_INVALID, "mipt_node_create: bad argument (1..64 GPUs)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MIPT_ERR_DEVICE, "no HIP device available");
+    struct KeepDevice {  // the caller's current device is the caller's
+        int dev = -1;
+        KeepDevice() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+        ~KeepDevice() { if (dev >= 0) (void)hipSetDevice(dev); }
+    } keep;
     std::vector<int> devs((size_t)ngpus);
     for (int i = 0; i < ngpus; i++) devs[(size_t)i] = devices ? devices[i] : i;
     bool distinct = true;
@@ -313,7 +370,12 @@ int mipt_node_create(const mipt_scene* scene, int ngpus, const int* devices, mip
             Rank& r = nd->ranks[(size_t)i];
             r.device = devs[(size_t)i];
             if (hipSetDevice(r.device) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&r.packed, hipEventDisableTiming) != hipSuccess) {
+                hipStreamCreateWithFlags(&r.xfer, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&r.packed, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&r.evPacked, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&r.evSent[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&r.evSent[1], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&r.evDone, hipEventDisableTiming) != hipSuccess) {
                 mipt_node_destroy(nd);
                 return fail(MIPT_ERR_DEVICE, "mipt_node_create: stream / event creation failed on device " + std::to_string(r.device));
             }
@@ -332,7 +394,14 @@ int mipt_node_create(const mipt_scene* scene, int ngpus, const int* devices, mip
             }
             for (int i = 0; i < ngpus; i++) nd->ranks[(size_t)i].comm = comms[(size_t)i];
             nd->useRccl = true;
+            // exactly the owned bytes, point to point, wherever RCCL has send / receive (MIPT_NODE_GATHER=gather keeps the
+            // one-call collective over padded slots; without ncclGather there is no choice)
+            const bool p2p = nd->rccl->Send && nd->rccl->Recv && nd->rccl->GroupStart && nd->rccl->GroupEnd;
+            const char* gv = getenv("MIPT_NODE_GATHER");
+            nd->exact = p2p && !(gv && std::string(gv) == "gather" && nd->rccl->Gather);
+            if (!nd->rccl->Gather) nd->exact = true;
         }
+        if (const char* av = getenv("MIPT_NODE_ASYNC")) nd->async = std::string(av) != "0";
         for (int i = 0; i < ngpus; i++) nd->threads.emplace_back(worker, nd, i);
     } catch (const std::exception& e) {
         if (nd) mipt_node_destroy(nd);
@@ -344,6 +413,8 @@ int mipt_node_create(const mipt_scene* scene, int ngpus, const int* devices, mip
 
 void mipt_node_destroy(mipt_node* nd) {
     if (!nd) return;
+    int callerDev = -1;
+    if (hipGetDevice(&callerDev) != hipSuccess) callerDev = -1;
     if (!nd->threads.empty()) {
         run_job(nd, JOB_QUIT);
         for (auto& t : nd->threads) t.join();
@@ -351,13 +422,17 @@ void mipt_node_destroy(mipt_node* nd) {
     for (Rank& r : nd->ranks) {
         (void)hipSetDevice(r.device);
         if (r.stream) (void)hipStreamSynchronize(r.stream);
+        if (r.xfer) (void)hipStreamSynchronize(r.xfer);
         if (r.comm && nd->rccl) (void)nd->rccl->CommDestroy(r.comm);
         if (r.ctx) mipt_context_destroy(r.ctx);
         if (r.frameMem) (void)hipFree(r.frameMem);
-        if (r.packed) (void)hipEventDestroy(r.packed);
+        for (hipEvent_t e : {r.packed, r.evPacked, r.evSent[0], r.evSent[1], r.evDone})
+            if (e) (void)hipEventDestroy(e);
+        if (r.xfer) (void)hipStreamDestroy(r.xfer);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
     delete nd;
+    if (callerDev >= 0) (void)hipSetDevice(callerDev);
 }
 
 int mipt_node_num_gpus(const mipt_node* nd) { return nd ? nd->n : 0; }
@@ -387,7 +462,9 @@ int mipt_node_render(mipt_node* nd, const mipt_camera* cam, const mipt_render_pa
             nd->layoutGen++;  // the workers lay their frame memory out again
         }
         nd->cam = *cam; nd->rp = *rp; nd->rgbHost = rgb_host;
+        if (nd->dead) return fail(MIPT_ERR_DEVICE, "mipt_node_render: an earlier gather failed and the communicator was aborted; make a new node");
         nd->failed.store(0);
+        nd->failedGather.store(0);
         nd->clear = !(rp->mode == MIPT_MODE_PATH && rp->sample_offset > 0);  // a progressive call continues its accumulation
         const auto t0 = std::chrono::steady_clock::now();
         run_job(nd, JOB_RENDER);
@@ -399,16 +476,34 @@ int mipt_node_render(mipt_node* nd, const mipt_camera* cam, const mipt_render_pa
         if (nd->ranks[(size_t)i].rc != MIPT_OK) {
             const int rc = nd->ranks[(size_t)i].rc;
             nd->key.clear();  // whatever state the ranks are in, the next call lays the frame out again
+            if (nd->failedGather.load() && nd->useRccl) nd->dead = true;
             return fail(rc, "rank " + std::to_string(i) + " (device " + std::to_string(nd->ranks[(size_t)i].device) + "): " + nd->ranks[(size_t)i].error);
         }
     return MIPT_OK;
 }
 
+int mipt_node_synchronize(mipt_node* nd) {
+    if (!nd) return fail(MIPT_ERR_INVALID, "mipt_node_synchronize: null node");
+    int callerDev = -1;
+    if (hipGetDevice(&callerDev) != hipSuccess) callerDev = -1;
+    int rc = MIPT_OK;
+    for (Rank& r : nd->ranks) {
+        if (hipSetDevice(r.device) != hipSuccess || hipStreamSynchronize(r.stream) != hipSuccess || hipStreamSynchronize(r.xfer) != hipSuccess)
+            rc = fail(MIPT_ERR_DEVICE, "mipt_node_synchronize: a stream of device " + std::to_string(r.device) + " failed");
+    }
+    if (callerDev >= 0) (void)hipSetDevice(callerDev);
+    return rc;
+}
+
 int mipt_node_get_stats(mipt_node* nd, mipt_stats* out, double* last_frame_ms) {
     if (!nd || !out) return fail(MIPT_ERR_INVALID, "mipt_node_get_stats: null argument");
+    int callerDev = -1;
+    if (hipGetDevice(&callerDev) != hipSuccess) callerDev = -1;
     mipt_stats sum{};
     for (Rank& r : nd->ranks) {
         mipt_stats s{};
+        (void)hipSetDevice(r.device);
+        (void)hipStreamSynchronize(r.xfer);  // (a call without a host buffer leaves its transfer enqueued)
         const int rc = mipt_context_get_stats(r.ctx, &s);
         if (rc != MIPT_OK) return rc;
         sum.rays_closest += s.rays_closest; sum.rays_occluded += s.rays_occluded;
@@ -416,7 +511,9 @@ int mipt_node_get_stats(mipt_node* nd, mipt_stats* out, double* last_frame_ms) {
         sum.ms_closest += s.ms_closest; sum.ms_occluded += s.ms_occluded; sum.ms_other += s.ms_other;
         sum.node_visits_closest += s.node_visits_closest; sum.tri_tests_closest += s.tri_tests_closest;
         sum.node_visits_occluded += s.node_visits_occluded; sum.tri_tests_occluded += s.tri_tests_occluded;
+        sum.launches_shade += s.launches_shade; sum.ms_shade += s.ms_shade;
     }
+    if (callerDev >= 0) (void)hipSetDevice(callerDev);
     *out = sum;
     if (last_frame_ms) *last_frame_ms = nd->lastMs;
     return MIPT_OK;

@@ -112,7 +112,7 @@ def test_bench_rccl_path_with_one_rank(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--force-dist"], env=env, capture_output=True, text=True, timeout=280)
+                        "--no-cpu-baseline", "--force-dist", "--native-node"], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -120,3 +120,46 @@ def test_bench_rccl_path_with_one_rank(tmp_path):
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 1000.0
     weak = out["config"]["weak_scaling"]
     assert weak is not None and weak["spp_per_step"] == 16 and abs(weak["value"] / out["value"] - 1.0) < 0.1
+    # ... and beside it the NATIVE node (mipt_node_render in a child process: one process, thread per GPU, RCCL), the
+    # same frame: same rays per step, a rate in the same range
+    nat = out["config"]["native_node"]
+    assert nat is not None and "error" not in nat, nat
+    assert nat["uses_rccl"] and nat["n_gpus"] == 1 and abs(nat["value"] / out["value"] - 1.0) < 0.15, nat
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_calls_without_a_host_buffer_return_enqueued_and_the_last_call_fetches_the_frame(B, setup, devices):
+    """a progressive sequence as configs[4] runs it: every call but the last leaves the frame on GPU 0 (the call returns
+    with its gather enqueued on the transfer stream, the next call's kernels run beside it, the two send slots are used
+    in turn); the last call fetches it.  1 + 1 + 1 + 2 samples == the one-context 5-sample frame bit for bit, with the
+    RCCL transport (one GPU) and with ranks sharing the GPU; then a fresh frame on the same node."""
+    scene, ctx, cam, ref_path, ref_direct = setup
+    node = B.Node(scene, devices=devices)
+    for rep in range(2):
+        for k in range(3):
+            assert node.render(cam, mode=B.MODE_PATH, spp=1, sample_offset=k, max_bounces=4, seed=3, readback=False) is None
+        img = node.render(cam, mode=B.MODE_PATH, spp=2, sample_offset=3, max_bounces=4, seed=3)
+        assert np.array_equal(bits(img), bits(ref_path)), (devices, rep)
+    node.render(cam, mode=B.MODE_DIRECT, readback=False)
+    node.synchronize()
+    assert np.array_equal(bits(node.render(cam, mode=B.MODE_DIRECT)), bits(ref_direct))
+
+
+def test_more_than_one_physical_gpu_or_a_stated_skip(B, setup):
+    """what a one-GPU box cannot run says so: on a machine with several GPUs this builds the node over ALL of them (one
+    RCCL communicator over distinct devices, grouped send / receive over xGMI) and compares its frames with the one-GPU
+    frames bit for bit -- the first multi-GPU run reports what ran instead of silently having run nothing"""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: ncclCommInitAll over distinct devices, the RCCL transfer across xGMI and WORLD_SIZE > 1 on "
+                    "the nccl backend have not run on this machine (the same code runs here with one GPU and with ranks sharing it)")
+    scene, ctx, cam, ref_path, ref_direct = setup
+    node = B.Node(scene, ngpus=n)
+    assert node.num_gpus == n and node.uses_rccl
+    for _ in range(2):
+        assert np.array_equal(bits(node.render(cam, mode=B.MODE_PATH, spp=5, max_bounces=4, seed=3)), bits(ref_path))
+    for k in range(3):
+        node.render(cam, mode=B.MODE_PATH, spp=1, sample_offset=k, max_bounces=4, seed=3, readback=False)
+    assert np.array_equal(bits(node.render(cam, mode=B.MODE_PATH, spp=2, sample_offset=3, max_bounces=4, seed=3)), bits(ref_path))
+    assert np.array_equal(bits(node.render(cam, mode=B.MODE_DIRECT)), bits(ref_direct))
