@@ -279,6 +279,12 @@ constexpr unsigned kPendMask = 15u;
 #ifndef PT_TUNE_WIDE_POOL_MAX
 #define PT_TUNE_WIDE_POOL_MAX 8192u
 #endif
+#ifndef PT_TUNE_WIDE_TAIL_BURST
+#define PT_TUNE_WIDE_TAIL_BURST 2   // once the queue is empty: visits between two votes (0: as while it is not).  r3, with the greedy rule below: a 64-ray launch 58 -> 47 us, 262,144 rays 94 -> 85 us, the 1/8 share of the bench frame 4.80 -> 4.77 ms (4: the same)
+#endif
+#ifndef PT_TUNE_WIDE_TAIL_GREEDY
+#define PT_TUNE_WIDE_TAIL_GREEDY 1  // once the queue is empty: the phase with more lanes to serve runs next
+#endif
 #ifndef PT_TUNE_WIDE_SHARE_MIN
 #define PT_TUNE_WIDE_SHARE_MIN 4  // idle lanes before a hand-over round is worth its instructions (tail of a launch only)
 #endif
@@ -293,7 +299,7 @@ constexpr unsigned kPendMask = 15u;
 #if PT_DIAG_TAIL
 // per wavefront of the last closest-hit launch: {start, queue-empty, end, hand-overs} (plain stores: atomics on a few words
 // from 4,096 wavefronts would themselves stretch the launch)
-__device__ unsigned long long g_tailDiag[4 * 4096];
+__device__ unsigned long long g_tailDiag[2 * 4 * 4096];  // [any-hit][wavefront][4]
 #endif
 
 // LDS of one block, declared by the kernels and handed to the body (a body inlined twice must not declare it twice)
@@ -745,6 +751,7 @@ __device__ __forceinline__ void wide_body(
         // ---- visits: lanes with a node to visit and room for one more leaf group ----
 #pragma unroll
         for (int b = 0; b < (ANYHIT ? PT_TUNE_WIDE_BURST_ANYHIT : PT_TUNE_WIDE_BURST); b++) {
+            if (PT_TUNE_WIDE_TAIL_BURST > 0 && SHARE && exhausted && b >= PT_TUNE_WIDE_TAIL_BURST) break;  // the tail: shorter turns, work spreads sooner
 #if PT_DIAG_UTIL == 1
             if (COUNT) { const unsigned long long ma = __ballot(w >= 0 && groups < kWideGroups); if (ma) { nv += (w >= 0 && groups < kWideGroups) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; } }
 #endif
@@ -902,8 +909,10 @@ __device__ __forceinline__ void wide_body(
         if (mPend != 0ull && (__popcll(mPend) >= __popcll(mCanVisit) ||
                               __popcll(mStuck) >= (ANYHIT ? PT_TUNE_WIDE_STUCK_ANYHIT : PT_TUNE_WIDE_STUCK))) {
 #else
+        const bool tailGreedy = PT_TUNE_WIDE_TAIL_GREEDY && SHARE && exhausted;
         if (mPend != 0ull && (__popcll(mPend) >= (ANYHIT ? PT_TUNE_WIDE_LEAF_ANYHIT : PT_TUNE_WIDE_LEAF) ||
-                              __popcll(mStuck) >= (ANYHIT ? PT_TUNE_WIDE_STUCK_ANYHIT : PT_TUNE_WIDE_STUCK) || mCanVisit == 0ull)) {
+                              __popcll(mStuck) >= (ANYHIT ? PT_TUNE_WIDE_STUCK_ANYHIT : PT_TUNE_WIDE_STUCK) || mCanVisit == 0ull ||
+                              (tailGreedy && __popcll(mPend) >= __popcll(mCanVisit)))) {
 #endif
             do {
                 // One round trip per iteration: a lane either opens the next leaf of its top group (the copy of the
@@ -957,7 +966,8 @@ __device__ __forceinline__ void wide_body(
 #if PT_TUNE_WIDE_GREEDY
             } while (mPend != 0ull && __popcll(mPend) >= __popcll(__ballot(w >= 0 && groups < kWideGroups)));
 #else
-            } while (__popcll(mPend) >= (ANYHIT ? PT_TUNE_WIDE_KEEP_ANYHIT : PT_TUNE_WIDE_KEEP));
+            } while (__popcll(mPend) >= (ANYHIT ? PT_TUNE_WIDE_KEEP_ANYHIT : PT_TUNE_WIDE_KEEP) ||
+                     (tailGreedy && mPend != 0ull && __popcll(mPend) >= __popcll(__ballot(w >= 0 && groups < kWideGroups))));
 #endif
             // ---- the verdicts: exact box predicate of every lane that holds an unverified best ----
             if (uLeaf >= 0) {
@@ -1093,11 +1103,12 @@ __device__ __forceinline__ void wide_body(
     }
 #endif
 #if PT_DIAG_TAIL
-    if (lane == 0 && !ANYHIT && gw < 4096u) {
-        g_tailDiag[4 * gw] = diagStart;
-        g_tailDiag[4 * gw + 1] = diagEmpty;
-        g_tailDiag[4 * gw + 2] = wall_clock64();
-        g_tailDiag[4 * gw + 3] = diagGifts;
+    if (lane == 0 && gw < 4096u) {
+        unsigned long long* dg = g_tailDiag + (ANYHIT ? 4 * 4096 : 0) + 4 * gw;
+        dg[0] = diagStart;
+        dg[1] = diagEmpty;
+        dg[2] = wall_clock64();
+        dg[3] = diagGifts;
     }
 #endif
     if (COUNT) {
@@ -1219,10 +1230,10 @@ void launch_trace_wide_both(hipStream_t st, const DevScene& s, const float4* ray
 #if PT_DIAG_TAIL
 // diagnostic builds only; not part of include/mipt.h
 extern "C" int mipt_debug_tail(unsigned long long* out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_tailDiag), 4 * 4096 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_tailDiag), 2 * 4 * 4096 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
         void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ptd::g_tailDiag)) != hipSuccess || hipMemset(p, 0, 4 * 4096 * sizeof(unsigned long long)) != hipSuccess) return -1;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ptd::g_tailDiag)) != hipSuccess || hipMemset(p, 0, 2 * 4 * 4096 * sizeof(unsigned long long)) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -62,3 +62,21 @@ def test_noalloc_entry_matches_trace_device_on_two_calls_in_a_row(B, ob, sf, nam
     finally:
         for p in (d_rays, d_hits, d_hits2):
             ctx.buffer_free(p)
+
+
+def test_noalloc_entry_runs_under_hip_graph_capture(B, sf, tmp_path):
+    """what the entry point exists for: a caller that cannot allocate.  tools/micro/capture_noalloc.cpp (HIP API only, a
+    process of its own) checks that a plain call leaves free device memory unchanged, then makes the call while its
+    stream is being CAPTURED into a HIP graph (hipStreamCaptureModeGlobal: a hipMalloc, a hipFree or a synchronisation
+    would fail the capture), launches the graph twice on fresh rays -- rays that are handed back among them -- and
+    compares the hits with mipt_trace_device's bit for bit.  (mipt_trace_device itself may allocate its hand-back list
+    and is not asked to pass this.)"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "micro", "capture_noalloc")
+    assert os.path.exists(exe), "tools/micro/capture_noalloc is built by path-tracer_amd/csrc/Makefile (__graft_entry__.build())"
+    mesh = B.Mesh.from_arrays(*sf.load_scene_arrays("cornellbox"))
+    flat = str(tmp_path / "cornellbox.miptsc")
+    B.save_scene_cache(flat, mesh, B.BVH(mesh))
+    r = subprocess.run([exe, flat], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and "capture ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

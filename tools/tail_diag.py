@@ -15,7 +15,7 @@ ctx = B.Context(scene, device=0)
 L = B.lib()
 pos = np.asarray(arrays[0], np.float32).reshape(-1, 3); lo, hi = pos.min(0), pos.max(0)
 rng = np.random.default_rng(1)
-buf = (C.c_ulonglong * (4 * 4096))()
+buf = (C.c_ulonglong * (2 * 4 * 4096))()
 for n in (64, 65536, 262144, 1 << 20, 1 << 22, 1 << 24):
     o = (lo + (hi - lo) * rng.uniform(0.05, 0.95, (n, 3))).astype(np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
@@ -24,7 +24,7 @@ for n in (64, 65536, 262144, 1 << 20, 1 << 22, 1 << 24):
         L.mipt_debug_tail(None, 1)
         ctx.trace(o, d)
         L.mipt_debug_tail(buf, 0)
-        a = np.frombuffer(buf, np.uint64).reshape(4096, 4).astype(np.float64)
+        a = np.frombuffer(buf, np.uint64).reshape(2, 4096, 4)[0].astype(np.float64)
         a = a[a[:, 2] > 0]
         start, empty, end, gifts = a[:, 0] / 100.0, a[:, 1] / 100.0, a[:, 2] / 100.0, a[:, 3]  # 100 MHz -> microseconds
         t0 = start.min()
