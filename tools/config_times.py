@@ -26,9 +26,10 @@ scenes = {}
 for label, name, w, h, mode, spp, bounces, steps in CONFIGS:
     if name not in scenes:
         arrays = sf.sponza_standin(2 if name == "sponza2" else 1) if name.startswith("sponza") else sf.load_scene_arrays(name)
+        tc = time.perf_counter()  # scene creation: validation, wide hierarchy on the host's cores, packing (no cache file)
         sc = sf.product_scene_from_mesh_arrays(*arrays, env=env, lights=sf.SPONZA_LIGHT if name.startswith("sponza") else sf.DEFAULT_LIGHT)
-        scenes[name] = (sc, B.Context(sc, device=0, stream=stream))
-    sc, ctx = scenes[name]
+        scenes[name] = (sc, B.Context(sc, device=0, stream=stream), time.perf_counter() - tc)
+    sc, ctx, create_s = scenes[name]
     cam = B.make_camera(w, h, sf.SPONZA_EYE, sf.SPONZA_LOOKAT) if name.startswith("sponza") else B.default_camera(w, h)
     accum = torch.zeros(h * w * 3, dtype=torch.float32, device=dev)
     rgb = torch.zeros(h * w * 3, dtype=torch.float32, device=dev)
@@ -49,7 +50,7 @@ for label, name, w, h, mode, spp, bounces, steps in CONFIGS:
     c = ctx.stats(); ctx.set_counting(False)
     print(json.dumps({"config": label, "ms_per_step": round(dt * 1e3, 3), "Mrays_per_step": round(rays / 1e6, 2),
                       "Mrays_per_s": round(rays / dt / 1e6, 1), "ms_per_frame_1spp": round(dt * 1e3 / spp, 3),
-                      "wide_nodes": sc.wide_nodes,
+                      "wide_nodes": sc.wide_nodes, "scene_create_s": round(create_s, 3),
                       "box_tests_per_closest_ray": round(c["node_visits_closest"] / max(c["rays_closest"], 1), 2),
                       "tri_tests_per_closest_ray": round(c["tri_tests_closest"] / max(c["rays_closest"], 1), 2),
                       "box_tests_per_shadow_ray": round(c["node_visits_occluded"] / max(c["rays_occluded"], 1), 2),
