@@ -69,8 +69,8 @@ typedef struct mipt_light {
  * interior node, else the leaf owns tri_index[leaf_first[i] ..
  * leaf_first[i]+leaf_count[i]) in BVHNode::triList order (C:1522-1524).
  * Triangle t: pos/nrm[9t..9t+8] (3 vertices x xyz), uv[6t..6t+5], mat_id[t].
- * A scene is ONE mesh with ONE BVH: the reference's Scene loops over `objects` (C:2060, C:2075, addObject C:2020),
- * but every configuration it ships adds exactly one; several meshes are merged into one by the caller.
+ * One description is ONE object (mesh + its BVH); the reference's Scene loops over `objects` (C:2060, C:2075, addObject
+ * C:2020): a scene of several objects is made from several descriptions by mipt_scene_create_multi below.
  * env_rgb: Image::pixels of Scene::background after Image::load's vertical
  * flip (C:214-219); may be NULL (env_width = 0): then a lookup returns black
  * (the reference divides by zero, C:2043).
@@ -260,6 +260,19 @@ int mipt_scene_create(const mipt_scene_desc* desc, mipt_scene** out);
  * foreign or damaged file is ignored and overwritten; a file that cannot be written is not an error.  Every rank of a
  * multi-GPU run and every start of mipt_render --cache uses this.  NULL or "": as mipt_scene_create. */
 int mipt_scene_create_cached(const mipt_scene_desc* desc, const char* wide_cache_path, mipt_scene** out);
+/* Scene::addObject (C:2020) n_objects times + Scene::preCalc's one BVH per object (C:2027-2035): a scene of several
+ * objects, each with its own mesh, materials, textures and BVH (objects[k] as mipt_scene_desc_fill made it; environment and
+ * lights are objects[0]'s).  Hits are those of Scene::intersect's loop over the objects (C:2070-2085): the smallest t, an
+ * exact tie going to the EARLIER object and, within one object, to the triangle its own walk meets first; Scene::isHit
+ * (C:2056-2068) is "some object is hit".  Triangle ids (mipt_trace) and material ids (hitrec) count through the objects in
+ * order: object k's triangle i is mipt_scene_object_tri_base(scene, k) + i.  wide_cache_path: as mipt_scene_create_cached,
+ * or NULL.  The bit-trail traversal (MIPT_TRAVERSAL_BITTRAIL) walks the objects one after the other as the reference
+ * does; with more than 64 objects the few rays the default traversal hands back take the literal walk, a lane per ray. */
+int mipt_scene_create_multi(const mipt_scene_desc* objects, int32_t n_objects, const char* wide_cache_path, mipt_scene** out);
+/* objects of a scene (1 for mipt_scene_create) and the first scene-wide triangle / material id of object k (-1: no such object) */
+int32_t mipt_scene_object_count(const mipt_scene*);
+int32_t mipt_scene_object_tri_base(const mipt_scene*, int32_t object);
+int32_t mipt_scene_object_material_base(const mipt_scene*, int32_t object);
 void mipt_scene_destroy(mipt_scene*);
 /* 1 when every box plane of the scene is 0 or of magnitude in [2^-61, 2^40] (and min <= max), so the traversal
  * kernel may replace the six IEEE divisions of AABB::intersect (C:574-580) by its exact per-ray reciprocal

@@ -54,6 +54,7 @@ def lib():
         L.orc_scene_set_env.argtypes = [vp, C.c_int, C.c_int, fp]
         L.orc_scene_set_lights.argtypes = [vp, C.c_int, fp]
         L.orc_scene_destroy.argtypes = [vp]
+        L.orc_scene_add_object.argtypes = [vp, vp]
         L.orc_build.argtypes = [vp]
         L.orc_bvh_stats.argtypes = [vp, ip]
         L.orc_bvh_export.argtypes = [vp, fp, fp, ip, ip, ip, ip, ip, ip, ip, ip, ip]
@@ -129,6 +130,14 @@ class OracleScene:
             self.set_env(env)
         self.set_lights(lights)
         L.orc_build(self.h)
+
+    def add_object(self, other):
+        """Scene::addObject (cs488.h:2020): `other` (an OracleScene of its own mesh, built) becomes the next object of
+        this scene; triangle and material ids reported by intersect() then count through all objects in order."""
+        self.objects = getattr(self, "objects", [])
+        self.objects.append(other)  # keeps it alive: the scene does not own it
+        lib().orc_scene_add_object(self.h, other.h)
+        return self
 
     def set_env(self, env):
         env = np.ascontiguousarray(env, np.float32)

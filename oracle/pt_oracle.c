@@ -91,12 +91,14 @@ typedef struct {
     f3 center;
 } Triangle;
 
+struct orc_scene;
 typedef struct {
     float t;
     f3 P, N;
     f2 T;
-    int material;  /* index instead of pointer */
-    int triId;     /* not in the reference's HitInfo: recorded where the hit is accepted */
+    int material;  /* index into the hit OBJECT's materials instead of the reference's pointer (C:772) */
+    const struct orc_scene *obj;  /* the object that was hit (what the reference's material pointer implies) */
+    int triId;     /* not in the reference's HitInfo: recorded where the hit is accepted; index within the object */
     float beta, gamma;
 } HitInfo;
 
@@ -141,6 +143,11 @@ typedef struct orc_scene {
     /* counters (instrumentation, not in the reference) */
     long long cntBox, cntTri;
     int maxDepth, maxLeaf;
+    /* Scene::objects (C:2006, addObject C:2020): this struct is object 0 AND the scene (environment, lights); further
+     * objects hang off `next`, each with its own triangles, materials and BVH (C:2030-2034).  triBase / matBase number
+     * triangles and materials through all objects, for the ids the exported functions report. */
+    struct orc_scene *next;
+    int triBase, matBase;
 } orc_scene;
 
 /* ------------------------------------------------------------------ */
@@ -215,6 +222,7 @@ static int raytraceTriangle(orc_scene *s, HitInfo *result, const Ray *ray, int t
     f3 phi = v3(alpha, beta, gamma);
     result->t = C / D;
     result->material = tri->idMaterial;
+    result->obj = s;
     result->P = mulcols3(tri->positions[0], tri->positions[1], tri->positions[2], phi);
     result->N = mulcols3(tri->normals[0], tri->normals[1], tri->normals[2], phi);
     result->T.x = (tri->texcoords[0].x * phi.x + tri->texcoords[1].x * phi.y) + tri->texcoords[2].x * phi.z;
@@ -586,24 +594,29 @@ static int bvh_intersect(orc_scene *s, int variant, HitInfo *h, const Ray *ray, 
     default: return bruteforce_intersect(s, h, ray, tMin, tMax);
     }
 }
-/* C:2070-2085 Scene::intersect (one object) */
+/* C:2070-2085 Scene::intersect: every object's BVH in turn, strict '<' between objects (the earlier object keeps a tie) */
 static int scene_intersect(orc_scene *s, int variant, HitInfo *minHit, const Ray *ray, float tMin, float tMax) {
     int hit = 0;
     HitInfo tempMinHit;
     minHit->t = FLT_MAX;
     minHit->triId = -1;
-    if (bvh_intersect(s, variant, &tempMinHit, ray, tMin, tMax)) {
-        if (tempMinHit.t < minHit->t) {
-            hit = 1;
-            *minHit = tempMinHit;
+    minHit->obj = s;
+    for (orc_scene *o = s; o; o = o->next) {
+        if (bvh_intersect(o, variant, &tempMinHit, ray, tMin, tMax)) {
+            if (tempMinHit.t < minHit->t) {
+                hit = 1;
+                *minHit = tempMinHit;
+            }
         }
     }
     return hit;
 }
-/* C:2056-2068 Scene::isHit: "does a full intersect return true" */
+/* C:2056-2068 Scene::isHit: "does a full intersect of some object return true", objects in order, stops at the first */
 static int scene_isHit(orc_scene *s, int variant, const Ray *ray, float tMin, float tMax) {
     HitInfo tempMinHit;
-    return bvh_intersect(s, variant, &tempMinHit, ray, tMin, tMax) ? 1 : 0;
+    for (orc_scene *o = s; o; o = o->next)
+        if (bvh_intersect(o, variant, &tempMinHit, ray, tMin, tMax)) return 1;
+    return 0;
 }
 
 /* ------------------------------------------------------------------ */
@@ -762,7 +775,7 @@ static f3 shade_pathtrace(Ctx *c, const HitInfo *hit, f3 viewDir, int level, flo
     float currEta = eta;
 
     while (1) {
-        const Material *m = &s->mats[recHit.material];
+        const Material *m = &recHit.obj->mats[recHit.material];
         const int capped = (c->max_bounces >= 0) && (currlevel - level >= c->max_bounces);
         if (m->type == MAT_LAMBERTIAN) {
             f3 L = v3(0.0f, 0.0f, 0.0f);
@@ -844,7 +857,7 @@ static f3 shade_pathtrace(Ctx *c, const HitInfo *hit, f3 viewDir, int level, flo
  * hemisphere-direction loop C:2437-2451 is dead (total_angles_h/v = 0). */
 static f3 shade(Ctx *c, const HitInfo *hit, f3 viewDir, int level, float eta) {
     orc_scene *s = c->s;
-    const Material *m = &s->mats[hit->material];
+    const Material *m = &hit->obj->mats[hit->material];
     if (m->type == MAT_LAMBERTIAN) {
         f3 L = v3(0.0f, 0.0f, 0.0f);
         f3 brdf, irradiance;
@@ -952,6 +965,16 @@ void orc_scene_set_lights(orc_scene *s, int n, const float *pos_wattage) {
         s->lights[i].wattage = v3(pos_wattage[6 * i + 3], pos_wattage[6 * i + 4], pos_wattage[6 * i + 5]);
     }
 }
+/* Scene::addObject (C:2020): obj (built by the caller with orc_build, as preCalc builds one BVH per object, C:2030-2034)
+ * becomes the scene's last object.  The scene does not own it. */
+void orc_scene_add_object(orc_scene *s, orc_scene *obj) {
+    orc_scene *last = s;
+    while (last->next) last = last->next;
+    obj->triBase = last->triBase + last->ntris;
+    obj->matBase = last->matBase + last->nmat;
+    obj->next = NULL;
+    last->next = obj;
+}
 void orc_scene_destroy(orc_scene *s) {
     if (!s) return;
     for (int i = 0; i < s->nmat; i++) free(s->texcopies[i]);
@@ -1004,7 +1027,7 @@ void orc_eye_rays(const Camera *cam, long long first, long long count, float *o,
  * counts[0..1] += node visits / box tests, triangle tests. */
 void orc_intersect(orc_scene *s, int variant, long long n, const float *o, const float *d, float tMin, float tMax,
                    int *tri_id, float *t, float *bary, float *hitrec, long long *counts) {
-    s->cntBox = s->cntTri = 0;
+    for (orc_scene *ob = s; ob; ob = ob->next) ob->cntBox = ob->cntTri = 0;
     for (long long i = 0; i < n; i++) {
         Ray r;
         r.o = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
@@ -1012,14 +1035,14 @@ void orc_intersect(orc_scene *s, int variant, long long n, const float *o, const
         HitInfo h;
         memset(&h, 0, sizeof h);
         int hit = scene_intersect(s, variant, &h, &r, tMin, tMax);
-        if (tri_id) tri_id[i] = hit ? h.triId : -1;
+        if (tri_id) tri_id[i] = hit ? h.obj->triBase + h.triId : -1;
         if (t) t[i] = hit ? h.t : FLT_MAX;
         if (bary) { bary[2 * i] = hit ? h.beta : 0.0f; bary[2 * i + 1] = hit ? h.gamma : 0.0f; }
         if (hitrec) {
             float *q = hitrec + 10 * i;
             if (hit) {
                 q[0] = h.t; q[1] = h.P.x; q[2] = h.P.y; q[3] = h.P.z; q[4] = h.N.x; q[5] = h.N.y; q[6] = h.N.z;
-                q[7] = h.T.x; q[8] = h.T.y; q[9] = (float)h.material;
+                q[7] = h.T.x; q[8] = h.T.y; q[9] = (float)(h.obj->matBase + h.material);
             } else {
                 q[0] = FLT_MAX;
                 for (int k = 1; k < 10; k++) q[k] = 0.0f;
@@ -1027,7 +1050,8 @@ void orc_intersect(orc_scene *s, int variant, long long n, const float *o, const
             }
         }
     }
-    if (counts) { counts[0] += s->cntBox; counts[1] += s->cntTri; }
+    if (counts)
+        for (orc_scene *ob = s; ob; ob = ob->next) { counts[0] += ob->cntBox; counts[1] += ob->cntTri; }
 }
 /* any-hit (C:1684-1705 via the threaded walk, or "full intersect returns true" C:2056-2068) */
 void orc_occluded(orc_scene *s, int variant, long long n, const float *o, const float *d, const float *tmin,
@@ -1036,8 +1060,12 @@ void orc_occluded(orc_scene *s, int variant, long long n, const float *o, const 
         Ray r;
         r.o = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
         r.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-        if (variant == ORC_THREADED) occluded[i] = (unsigned char)threaded_isHit(s, &r, tmin[i], tmax[i]);
-        else occluded[i] = (unsigned char)scene_isHit(s, variant, &r, tmin[i], tmax[i]);
+        if (variant == ORC_THREADED) {
+            occluded[i] = 0;
+            for (orc_scene *ob = s; ob && !occluded[i]; ob = ob->next) occluded[i] = (unsigned char)threaded_isHit(ob, &r, tmin[i], tmax[i]);
+        } else {
+            occluded[i] = (unsigned char)scene_isHit(s, variant, &r, tmin[i], tmax[i]);
+        }
     }
 }
 void orc_background(const orc_scene *s, long long n, const float *dir, float *rgb) {

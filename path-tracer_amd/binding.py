@@ -79,7 +79,7 @@ SYMBOLS = [
     "mipt_bvh_node_min", "mipt_bvh_node_max", "mipt_bvh_id_hit", "mipt_bvh_id_miss", "mipt_bvh_leaf_first",
     "mipt_bvh_leaf_count", "mipt_bvh_id_left", "mipt_bvh_id_right", "mipt_bvh_id_parent", "mipt_bvh_id_sibling",
     "mipt_bvh_tri_index", "mipt_bvh_destroy",
-    "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_create_cached", "mipt_scene_destroy", "mipt_scene_exact_reciprocal", "mipt_scene_wide_nodes", "mipt_scene_wide_hash", "mipt_scene_selfcheck_wide",
+    "mipt_scene_desc_fill", "mipt_scene_create", "mipt_scene_create_cached", "mipt_scene_create_multi", "mipt_scene_object_count", "mipt_scene_object_tri_base", "mipt_scene_object_material_base", "mipt_scene_destroy", "mipt_scene_exact_reciprocal", "mipt_scene_wide_nodes", "mipt_scene_wide_hash", "mipt_scene_selfcheck_wide",
     "mipt_context_create", "mipt_context_destroy", "mipt_context_arena_bytes",
     "mipt_trace", "mipt_trace_device", "mipt_trace_device_noalloc", "mipt_occluded", "mipt_eye_rays", "mipt_background",
     "mipt_selftest_fast_division", "mipt_selftest_vec_ops", "mipt_buffer_alloc", "mipt_buffer_free", "mipt_buffer_zero", "mipt_buffer_upload", "mipt_buffer_download",
@@ -160,6 +160,10 @@ def lib():
     L.mipt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(vp)]
     L.mipt_scene_create_cached.argtypes = [C.POINTER(SceneDesc), C.c_char_p, C.POINTER(vp)]
     L.mipt_scene_wide_hash.argtypes = [vp]
+    L.mipt_scene_create_multi.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.c_char_p, C.POINTER(vp)]
+    L.mipt_scene_object_count.argtypes = [vp]
+    L.mipt_scene_object_tri_base.argtypes = [vp, C.c_int32]
+    L.mipt_scene_object_material_base.argtypes = [vp, C.c_int32]
     L.mipt_scene_wide_hash.restype = C.c_uint64
     L.mipt_context_create.argtypes = [vp, C.c_int, vp, C.POINTER(vp)]
     L.mipt_context_arena_bytes.argtypes = [vp]
@@ -467,26 +471,45 @@ def file_fingerprint(path):
 
 
 class Scene:
-    """Scene of the reference (C:2004-2036): one object, lights, background."""
+    """Scene of the reference (C:2004-2036): objects, lights, background."""
 
     def __init__(self, mesh, bvh=None, env=None, lights=((3.0, 3.0, 3.0, 1000.0, 1000.0, 1000.0),), wide_cache=None):
-        """wide_cache: path of a file that keeps the library's own hierarchy above the leaves (mipt_scene_create_cached)"""
-        self.mesh = mesh
-        self.bvh = bvh if bvh is not None else BVH(mesh)
+        """mesh: a Mesh, or a list of them = Scene::addObject once per mesh (cs488.h:2020; bvh then None or a list);
+        wide_cache: path of a file that keeps the library's own hierarchy above the leaves (mipt_scene_create_cached)"""
+        meshes = list(mesh) if isinstance(mesh, (list, tuple)) else [mesh]
+        bvhs = list(bvh) if isinstance(bvh, (list, tuple)) else [bvh] + [None] * (len(meshes) - 1)
+        self.meshes = meshes
+        self.bvhs = [b if b is not None else BVH(m) for m, b in zip(meshes, bvhs)]
+        self.mesh, self.bvh = self.meshes[0], self.bvhs[0]
         self.env = env
         self.lights = (Light * max(1, len(lights)))()
         for i, l in enumerate(lights):
             self.lights[i].position[:] = l[0:3]
             self.lights[i].wattage[:] = l[3:6]
-        self.desc = SceneDesc()
-        check(lib().mipt_scene_desc_fill(mesh.h, self.bvh.h, env.h if env is not None else None, self.lights,
-                                         len(lights), C.byref(self.desc)))
+        self.descs = (SceneDesc * len(meshes))()
+        for k, (m, b) in enumerate(zip(self.meshes, self.bvhs)):
+            check(lib().mipt_scene_desc_fill(m.h, b.h, env.h if env is not None else None, self.lights, len(lights),
+                                             C.byref(self.descs[k])))
+        self.desc = self.descs[0]
         h = C.c_void_p()
-        if wide_cache:
+        if len(meshes) > 1:
+            check(lib().mipt_scene_create_multi(self.descs, len(meshes), os.fsencode(wide_cache) if wide_cache else None, C.byref(h)))
+        elif wide_cache:
             check(lib().mipt_scene_create_cached(C.byref(self.desc), os.fsencode(wide_cache), C.byref(h)))
         else:
             check(lib().mipt_scene_create(C.byref(self.desc), C.byref(h)))
         self.h = h
+
+    @property
+    def object_count(self):
+        return int(lib().mipt_scene_object_count(self.h))
+
+    def object_tri_base(self, k):
+        """scene-wide id of object k's triangle 0 (mipt_scene_object_tri_base)"""
+        return int(lib().mipt_scene_object_tri_base(self.h, k))
+
+    def object_material_base(self, k):
+        return int(lib().mipt_scene_object_material_base(self.h, k))
 
     @property
     def wide_hash(self):

@@ -82,6 +82,8 @@ struct mipt_scene {
     // 4-wide tree over the same leaves for the order-free traversal (device_scene.hpp "wide")
     std::vector<float4> wnodes, leafBox, leafHead;
     std::vector<int> nodeRight;
+    std::vector<int> roots;     // device numbering: the root of every object's tree (one entry for a scene of one object)
+    std::vector<int> objTriBase, objMatBase;  // mipt_scene_create_multi: first global triangle / material id of every object
     std::vector<int4> btLinks;  // StacklessBVH2 links in device numbering
     bool hasSpecular = false;   // some material is metal or glass: only then does shade() recurse (C:2455-2490)
     bool btOk = false;
@@ -127,10 +129,26 @@ static float half_value(unsigned short h) {
 // Is the threaded tree a proper binary tree (every interior node's idHit = its left child, that child's idMiss = the
 // right child, both further on in preorder, every node but the root with exactly one parent)?  The bit-trail links
 // and k_trace_slow's right-child table need exactly this; the box planes play no part in it.
-static bool is_binary_tree(const mipt_scene_desc* d) {
+// Several objects per scene (Scene::objects, cs488.h:2006; mipt_scene_create_multi) arrive as a FOREST in one node array:
+// the trees one after the other, every link by which the walk leaves tree k (0 in the object's own numbering) pointing at
+// the root of tree k + 1.  The literal walk then visits the objects in order, exactly as Scene::intersect's loop does
+// (cs488.h:2075-2083: strict '<' between objects = strict '<' in visit order).  The roots are the chain 0 -> id_miss[0] ->
+// ...; a single tree is a forest of one.
+static bool forest_roots(const mipt_scene_desc* d, std::vector<int>& roots) {
+    roots.clear();
+    const int n = d->n_nodes;
+    for (int r = 0;;) {
+        roots.push_back(r);
+        const int nx = d->id_miss[r];
+        if (nx == 0) return true;
+        if (!(nx > r && nx < n)) return false;
+        r = nx;
+    }
+}
+static bool is_binary_tree(const mipt_scene_desc* d, const std::vector<int>& roots) {
     const int n = d->n_nodes;
     std::vector<char> seen((size_t)n, 0);
-    seen[0] = 1;
+    for (const int r : roots) seen[(size_t)r] = 1;
     for (int i = 0; i < n; i++) {
         if (d->leaf_count[i] > 0) continue;
         const int l = d->id_hit[i];
@@ -138,6 +156,7 @@ static bool is_binary_tree(const mipt_scene_desc* d) {
         const int r = d->id_miss[l];
         if (!(r > l && r < n)) return false;
         if (seen[l] || seen[r]) return false;
+        if (d->id_miss[r] != d->id_miss[i]) return false;  // the walk leaves the right subtree where it leaves the node's (cs488.h:1655-1658)
         seen[l] = seen[r] = 1;
     }
     for (int i = 0; i < n; i++)
@@ -549,7 +568,10 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
         // the premise about the REFERENCE's tree, whichever hierarchy is walked: a proper binary tree, boxes nested
         const int n = d->n_nodes;
         std::vector<char> seen((size_t)n, 0);
-        seen[0] = 1;
+        std::vector<int> roots;
+        if (!forest_roots(d, roots)) return false;
+        if (roots.size() > 1 && !rebuilt) return false;  // several objects: only a hierarchy of our own joins them under one root
+        for (const int r : roots) seen[(size_t)r] = 1;
         for (int i = 0; i < n; i++) bt.add(&d->node_min[3 * i], &d->node_max[3 * i], d->leaf_count[i] > 0 ? i : -1);
         for (int i = 0; i < n; i++) {
             if (d->leaf_count[i] > 0) continue;
@@ -558,6 +580,7 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
             const int r = d->id_miss[l];
             if (!(r > l && r < n)) return false;
             if (seen[l] || seen[r]) return false;  // every node has exactly one parent
+            if (d->id_miss[r] != d->id_miss[i]) return false;  // ... and the links are the threading of that tree (cs488.h:1655-1658)
             seen[l] = seen[r] = 1;
             bt.left[(size_t)i] = l; bt.right[(size_t)i] = r;
             for (const int c : {l, r})
@@ -1169,6 +1192,96 @@ int mipt_scene_create_cached(const mipt_scene_desc* d, const char* wide_cache_pa
     return scene_create_impl(d, (wide_cache_path && *wide_cache_path) ? wide_cache_path : nullptr, out);
 }
 
+// Scene::addObject (cs488.h:2020) + preCalc's one BVH per object (cs488.h:2030-2034).  The objects are laid end to end in
+// ONE description -- nodes, leaf ranges, triangles, materials and textures renumbered by their offsets -- and every link
+// by which the walk leaves object k's tree (0 there) is pointed at the root of object k + 1: the literal walk then visits
+// the objects in the order Scene::intersect's loop does (cs488.h:2075), its strict '<' in visit order is that loop's strict
+// '<' between objects, and every other traversal sees one scene whose leafTris order is (object, the object's own order),
+// which is exactly the reference's tie-break.  Environment and lights are the first object's.
+int mipt_scene_create_multi(const mipt_scene_desc* objs, int32_t n_objects, const char* wide_cache_path, mipt_scene** out) {
+    if (!objs || !out || n_objects <= 0) return fail(MIPT_ERR_INVALID, "mipt_scene_create_multi: null argument or no objects");
+    const char* cache = (wide_cache_path && *wide_cache_path) ? wide_cache_path : nullptr;
+    return guarded("mipt_scene_create_multi", [&]() -> int {
+        std::vector<float> nodeMin, nodeMax, pos, nrm, uv;
+        std::vector<int32_t> idHit, idMiss, leafFirst, leafCount, triIndex, matId;
+        std::vector<mipt_material> mats;
+        std::vector<mipt_texture> texs;
+        std::vector<int> triBase, matBase;
+        long long nNodes = 0, nTriIndex = 0, nTris = 0;
+        for (int k = 0; k < n_objects; k++) {
+            const mipt_scene_desc& d = objs[k];
+            if (d.n_nodes <= 0 || d.n_tris <= 0 || d.n_tri_index <= 0 || !d.node_min || !d.node_max || !d.id_hit || !d.id_miss ||
+                !d.leaf_first || !d.leaf_count || !d.tri_index || !d.pos || !d.nrm || !d.uv || !d.mat_id || d.n_materials <= 0 ||
+                !d.materials || d.n_textures < 0 || (d.n_textures && !d.textures))
+                return fail(MIPT_ERR_INVALID, "mipt_scene_create_multi: an object lacks geometry or materials");
+            nNodes += d.n_nodes; nTriIndex += d.n_tri_index; nTris += d.n_tris;
+        }
+        if (nNodes > 0x7fffffffll || nTriIndex > 0x7fffffffll || nTris > 0x7fffffffll)
+            return fail(MIPT_ERR_LIMIT, "mipt_scene_create_multi: the objects together exceed 2^31 nodes or triangles");
+        int nodeOfs = 0, triIdxOfs = 0, triOfs = 0;
+        for (int k = 0; k < n_objects; k++) {
+            const mipt_scene_desc& d = objs[k];
+            const int nextRoot = k + 1 < n_objects ? nodeOfs + d.n_nodes : 0;  // where the walk goes when it leaves this tree
+            const int mOfs = (int)mats.size(), tOfs = (int)texs.size();
+            triBase.push_back(triOfs); matBase.push_back(mOfs);
+            nodeMin.insert(nodeMin.end(), d.node_min, d.node_min + (size_t)3 * d.n_nodes);
+            nodeMax.insert(nodeMax.end(), d.node_max, d.node_max + (size_t)3 * d.n_nodes);
+            for (int i = 0; i < d.n_nodes; i++) {
+                const int h = d.id_hit[i], m = d.id_miss[i];
+                // links are checked again on the merged arrays (forward or 0); here only: stay inside the own tree
+                if (h < 0 || h >= d.n_nodes || m < 0 || m >= d.n_nodes) return fail(MIPT_ERR_INVALID, "mipt_scene_create_multi: a link leaves its object's tree");
+                idHit.push_back(h == 0 ? nextRoot : h + nodeOfs);
+                idMiss.push_back(m == 0 ? nextRoot : m + nodeOfs);
+                leafFirst.push_back(d.leaf_count[i] > 0 ? d.leaf_first[i] + triIdxOfs : d.leaf_first[i]);
+                leafCount.push_back(d.leaf_count[i]);
+            }
+            for (int j = 0; j < d.n_tri_index; j++) {
+                if (d.tri_index[j] < 0 || d.tri_index[j] >= d.n_tris) return fail(MIPT_ERR_INVALID, "bad tri_index entry");
+                triIndex.push_back(d.tri_index[j] + triOfs);
+            }
+            pos.insert(pos.end(), d.pos, d.pos + (size_t)9 * d.n_tris);
+            nrm.insert(nrm.end(), d.nrm, d.nrm + (size_t)9 * d.n_tris);
+            uv.insert(uv.end(), d.uv, d.uv + (size_t)6 * d.n_tris);
+            for (int t = 0; t < d.n_tris; t++) {
+                if (d.mat_id[t] < 0 || d.mat_id[t] >= d.n_materials) return fail(MIPT_ERR_INVALID, "mat_id out of range");
+                matId.push_back(d.mat_id[t] + mOfs);
+            }
+            for (int i = 0; i < d.n_materials; i++) {
+                mipt_material m = d.materials[i];
+                if (m.tex_id >= d.n_textures) return fail(MIPT_ERR_INVALID, "material tex_id out of range");
+                if (m.tex_id >= 0) m.tex_id += tOfs;
+                mats.push_back(m);
+            }
+            texs.insert(texs.end(), d.textures, d.textures + d.n_textures);
+            nodeOfs += d.n_nodes; triIdxOfs += d.n_tri_index; triOfs += d.n_tris;
+        }
+        mipt_scene_desc m = objs[0];  // environment and lights
+        m.n_nodes = nodeOfs; m.node_min = nodeMin.data(); m.node_max = nodeMax.data();
+        m.id_hit = idHit.data(); m.id_miss = idMiss.data(); m.leaf_first = leafFirst.data(); m.leaf_count = leafCount.data();
+        m.n_tri_index = triIdxOfs; m.tri_index = triIndex.data();
+        m.n_tris = triOfs; m.pos = pos.data(); m.nrm = nrm.data(); m.uv = uv.data(); m.mat_id = matId.data();
+        m.n_materials = (int32_t)mats.size(); m.materials = mats.data();
+        m.n_textures = (int32_t)texs.size(); m.textures = texs.empty() ? nullptr : texs.data();
+        mipt_scene* sc = nullptr;
+        const int rc = scene_create_impl(&m, cache, &sc);
+        if (rc != MIPT_OK) return rc;
+        sc->objTriBase = triBase; sc->objMatBase = matBase;
+        *out = sc;
+        return MIPT_OK;
+    });
+}
+int32_t mipt_scene_object_count(const mipt_scene* s) { return s ? (int32_t)s->roots.size() : 0; }
+int32_t mipt_scene_object_tri_base(const mipt_scene* s, int32_t object) {
+    if (!s || object < 0) return -1;
+    if (s->objTriBase.empty()) return object == 0 ? 0 : -1;
+    return object < (int32_t)s->objTriBase.size() ? s->objTriBase[(size_t)object] : -1;
+}
+int32_t mipt_scene_object_material_base(const mipt_scene* s, int32_t object) {
+    if (!s || object < 0) return -1;
+    if (s->objMatBase.empty()) return object == 0 ? 0 : -1;
+    return object < (int32_t)s->objMatBase.size() ? s->objMatBase[(size_t)object] : -1;
+}
+
 }  // extern "C"
 
 namespace {
@@ -1207,7 +1320,11 @@ int scene_create_impl(const mipt_scene_desc* d, const char* wide_cache_path, mip
             };
             std::vector<char> top((size_t)n, 0);
             std::priority_queue<std::pair<float, int>> pq;
-            pq.push({area(0), 0});
+            {
+                std::vector<int> seeds;
+                if (!forest_roots(d, seeds)) seeds.assign(1, 0);
+                for (const int r : seeds) pq.push({area(r), r});  // several objects: every tree's root is met by every ray
+            }
             int nTop = 0;
             while (!pq.empty() && nTop < ptd::kTopNodes) {
                 const int i = pq.top().second;
@@ -1287,7 +1404,8 @@ int scene_create_impl(const mipt_scene_desc* d, const char* wide_cache_path, mip
             if (!s->wideOk) { s->wnodes.clear(); s->leafBox.clear(); s->leafHead.clear(); s->nWide = 0; }
             if (wide_cache_path) save_wide_cache(wide_cache_path, key, s);
         }
-        if (is_binary_tree(d)) {  // right child = where the left subtree's walk exits; independent of the wide tree and of the planes
+        if (!forest_roots(d, s->roots)) s->roots.assign(1, 0);
+        if (is_binary_tree(d, s->roots)) {  // right child = where the left subtree's walk exits; independent of the wide tree and of the planes
             s->nodeRight.assign((size_t)n, 0);
             s->btLinks.assign((size_t)n, make_int4(0, 0, 0, 0));  // root: idParent = idSibling = 0, C:1716-1717
             std::vector<int> depthOf((size_t)n, 0);
@@ -1303,8 +1421,9 @@ int scene_create_impl(const mipt_scene_desc* d, const char* wide_cache_path, mip
                 if (depthOf[l] > maxDepth) maxDepth = depthOf[l];
             }
             s->btOk = maxDepth <= 31;  // the reference's 32-bit trail holds one bit per level
-            s->slowOk = maxDepth <= 96;  // k_trace_slow: depth < kSlowReserve - 128 (since round 2 the wide tree no longer bounds the given tree's depth)
+            s->slowOk = maxDepth <= 96 && s->roots.size() <= 64;  // k_trace_slow: depth < kSlowReserve - 128 (since round 2 the wide tree no longer bounds the given tree's depth); its walk starts with every root on the stack
         }
+        for (int& r : s->roots) r = perm[(size_t)r];  // device numbering
         // textures -> one byte pool
         std::vector<int> texOfs((size_t)d->n_textures, 0);
         for (int i = 0; i < d->n_textures; i++) {
@@ -1496,7 +1615,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t szLeafHead = align256(s->leafHead.size() * sizeof(float4) + 16);
     const size_t szRight = align256(s->nodeRight.size() * sizeof(int) + 16);
     const size_t szBt = align256(s->btLinks.size() * sizeof(int4) + 16);
-    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights + szWide + szLeafBox + szLeafHead + szRight + szBt;
+    const size_t szRoots = align256(s->roots.size() * sizeof(int) + 16);
+    const size_t total = szNodes + szLeaf + szAttr + szMat + szTex + szEnv + szLights + szWide + szLeafBox + szLeafHead + szRight + szBt + szRoots;
     std::vector<unsigned char> stage(total, 0);
     size_t o = 0;
     const size_t oNodes = o; memcpy(&stage[o], s->nodes.data(), s->nodes.size() * sizeof(float4)); o += szNodes;
@@ -1510,7 +1630,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     const size_t oLeafBox = o; if (!s->leafBox.empty()) memcpy(&stage[o], s->leafBox.data(), s->leafBox.size() * sizeof(float4)); o += szLeafBox;
     const size_t oLeafHead = o; if (!s->leafHead.empty()) memcpy(&stage[o], s->leafHead.data(), s->leafHead.size() * sizeof(float4)); o += szLeafHead;
     const size_t oRight = o; if (!s->nodeRight.empty()) memcpy(&stage[o], s->nodeRight.data(), s->nodeRight.size() * sizeof(int)); o += szRight;
-    const size_t oBt = o; if (!s->btLinks.empty()) memcpy(&stage[o], s->btLinks.data(), s->btLinks.size() * sizeof(int4));
+    const size_t oBt = o; if (!s->btLinks.empty()) memcpy(&stage[o], s->btLinks.data(), s->btLinks.size() * sizeof(int4)); o += szBt;
+    const size_t oRoots = o; if (!s->roots.empty()) memcpy(&stage[o], s->roots.data(), s->roots.size() * sizeof(int));
     if (hipMalloc(&c->arena, total) != hipSuccess) return fail(MIPT_ERR_DEVICE, "hipMalloc(arena) failed");
     c->arenaBytes = total;
     if (hipMemcpy(c->arena, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1536,6 +1657,8 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.leafHead = (const float4*)(base + oLeafHead);
     c->ds.nodeRight = (const int*)(base + oRight);
     c->ds.btLinks = (const int4*)(base + oBt);
+    c->ds.roots = (const int*)(base + oRoots);
+    c->ds.nRoots = (int)s->roots.size();
     c->ds.btOk = s->btOk ? 1 : 0;
     c->ds.slowOk = s->slowOk ? 1 : 0;
     c->hasSpecular = s->hasSpecular;

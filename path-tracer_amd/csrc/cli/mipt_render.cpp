@@ -4,6 +4,8 @@
 // host, upload the arena, render on the GPU, write the image.
 //
 //   mipt_render --scene cornellbox.obj [--env probe.hdr] [--width 512 --height 384]
+//               [--add-scene more.obj]... further objects of the same scene (Scene::addObject, cs488.h:2020), each with
+//                                        its own BVH, in this order (mipt_scene_create_multi)
 //               [--mode primary|direct|path] [--spp 16] [--bounces 4] [--seed 1]
 //               [--eye x y z] [--lookat x y z] [--light x y z w] [--device 0]
 //               [--out image.png] [--out-hdr image.hdr] [--out-pfm image.pfm]
@@ -29,6 +31,7 @@ static void die(const char* what) {
 
 int main(int argc, char** argv) {
     std::string scenePath, envPath, outPng, outHdr, outPfm, cachePath;
+    std::vector<std::string> morePaths;
     mipt_camera cam{};
     cam.width = 512; cam.height = 384;  // globalWidth / globalHeight, cs488.h:45-46
     cam.eye[2] = 1.5f;                  // cs488.h:81-83
@@ -44,6 +47,7 @@ int main(int argc, char** argv) {
         auto need = [&](int k) { if (i + k >= argc) { fprintf(stderr, "missing value after %s\n", argv[i]); exit(2); } };
         std::string a = argv[i];
         if (a == "--scene") { need(1); scenePath = argv[++i]; }
+        else if (a == "--add-scene") { need(1); morePaths.push_back(argv[++i]); }
         else if (a == "--env") { need(1); envPath = argv[++i]; }
         else if (a == "--width") { need(1); cam.width = atoi(argv[++i]); }
         else if (a == "--height") { need(1); cam.height = atoi(argv[++i]); }
@@ -122,7 +126,22 @@ int main(int argc, char** argv) {
         // the tree, the leaf order, the positions and the light: mipt_scene_create_cached), so a second start builds nothing
         const auto t0 = std::chrono::steady_clock::now();
         const std::string widePath = cachePath.empty() ? std::string() : cachePath + ".wide";
-        if (mipt_scene_create_cached(&desc, widePath.c_str(), &scene) != MIPT_OK) die("scene");
+        if (morePaths.empty()) {
+            if (mipt_scene_create_cached(&desc, widePath.c_str(), &scene) != MIPT_OK) die("scene");
+        } else {
+            std::vector<mipt_scene_desc> descs{desc};
+            for (const std::string& path : morePaths) {  // parsed and built every time: the flat cache holds the first object
+                mipt_mesh* m = nullptr;
+                mipt_bvh* b = nullptr;
+                if (mipt_mesh_load_obj(path.c_str(), &m) != MIPT_OK) die(path.c_str());
+                if ((allAxes ? mipt_bvh_build_all_axes(m, &b) : mipt_bvh_build(m, &b)) != MIPT_OK) die("BVH build");
+                mipt_scene_desc d;
+                if (mipt_scene_desc_fill(m, b, env, &light, 1, &d) != MIPT_OK) die("scene description");
+                printf("Added \"%s\" with %d triangles.\n", path.c_str(), mipt_mesh_num_triangles(m));
+                descs.push_back(d);  // m and b stay alive until the process ends
+            }
+            if (mipt_scene_create_multi(descs.data(), (int32_t)descs.size(), widePath.c_str(), &scene) != MIPT_OK) die("scene");
+        }
         printf("Scene ready in %.1f ms (%d wide nodes%s).\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
                mipt_scene_wide_nodes(scene), widePath.empty() ? "" : ", hierarchy cache beside the scene cache");
     }

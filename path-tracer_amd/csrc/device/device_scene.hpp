@@ -66,6 +66,8 @@ struct DevScene {
     const float4* leafHead;
     const int* nodeRight;   // right child of every interior node (device numbering; 0 for leaves), only when nWide > 0
     const int4* btLinks;    // {idRight, idParent, idSibling, 0} per node (device numbering): StacklessBVH2's links, only when btOk
+    const int* roots;       // the root of every object's tree (device numbering; Scene::objects, cs488.h:2006): nRoots >= 1.  The
+    int nRoots;             // literal walk needs none of it (tree k's exits lead to root k + 1); k_trace_slow and k_trace_bittrail do
     int btOk;               // the tree is a verified binary tree of depth <= 31: k_trace_bittrail may run
     int slowOk;             // ... of depth <= 96: k_trace_slow's node stack holds every state of its walk (deeper trees hand
                             // their few awkward rays to the literal k_trace, a lane per ray)

@@ -57,14 +57,21 @@ __global__ __launch_bounds__(kBlock) void k_trace_bittrail(DevScene s, const flo
         const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
         const vec3 o{r0.x, r0.y, r0.z}, d{r1.x, r1.y, r1.z};
         const float tMin = r0.w, tMax = r1.w;
-        int node = 0, trail = 0;
+        // Scene::intersect / isHit (C:2056-2085): every object's BVH in turn, each traversal starting afresh (its own minHit,
+        // its own trail); between objects the strict '<' of C:2078, and isHit stops at the first object that reports a hit
+        bool sceneHit = false;
+        int sceneTri = -1;
+        float sceneT = 3.402823466e+38f, sceneB = 0.0f, sceneG = 0.0f;  // minHit.t = FLT_MAX, C:2073
+        for (int ob = 0; ob < s.nRoots; ob++) {
+        const int root = s.roots[ob];
+        int node = root, trail = 0;
         bool hit = false;
         int bestTri = -1;
         float minT = 3.402823466e+38f, bestB = 0.0f, bestG = 0.0f;  // minHit.t = FLT_MAX, C:1738
         float tTmp = 0.0f;
         long long steps = 0;
         if (COUNT) nv++;
-        bool walking = box_hit_t(nodes[0], nodes[1], o, d, tTmp);  // C:1743
+        bool walking = box_hit_t(nodes[2 * (size_t)root], nodes[2 * (size_t)root + 1], o, d, tTmp);  // C:1743
         while (walking) {
             // descend until you can't, C:1749-1771
             int link = f2i(nodes[2 * (size_t)node + 1].w);
@@ -115,10 +122,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_bittrail(DevScene s, const flo
                 if (tTmp < minT) break;
             }
         }
+        if (hit && minT < sceneT) { sceneHit = true; sceneTri = bestTri; sceneT = minT; sceneB = bestB; sceneG = bestG; }  // C:2077-2081
+        if (ANYHIT && hit) { sceneHit = true; break; }  // C:2062-2065
+        }
         if (ANYHIT) {
-            if (hit) occ[target ? (unsigned)target[slot] : slot] = 1;  // Scene::isHit, C:2056-2068: intersect() != false
+            if (sceneHit) occ[target ? (unsigned)target[slot] : slot] = 1;  // Scene::isHit, C:2056-2068: intersect() != false
         } else {
-            hits[raySlot] = make_float4(i2f(hit ? bestTri : -1), hit ? minT : 3.402823466e+38f, bestB, bestG);
+            hits[raySlot] = make_float4(i2f(sceneHit ? sceneTri : -1), sceneHit ? sceneT : 3.402823466e+38f, sceneB, sceneG);
         }
     }
     if (COUNT) {

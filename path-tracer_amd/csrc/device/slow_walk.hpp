@@ -38,8 +38,8 @@ __device__ __forceinline__ void slow_walk_wave(const DevScene& s, const vec3 o, 
 #define PT_SLOW_AT(i) stack[((i) >> 6) * ROW + ((i) & 63)]
     bestTri = -1; bestSeq = 0x7fffffff;
     bestT = 3.402823466e+38f; bestB = 0.0f; bestG = 0.0f;
-    int top = 1;
-    if (lane == 0) PT_SLOW_AT(0) = 0;
+    int top = s.nRoots;  // <= 64 (DevScene::slowOk): the root of every object's tree; the order is free
+    if (lane < top) PT_SLOW_AT(lane) = s.roots[lane];
     wave_lds_sync();
     while (top > 0) {
         const int take = top > capacity - kSlowReserve ? 1 : (top < 64 ? top : 64);
