@@ -547,7 +547,7 @@ def native_node_child(ngpus, steps, warmup, detail):
     return 0
 
 
-def time_native_node(ngpus, steps, warmup, detail, limit=240.0):
+def time_native_node(ngpus, steps, warmup, detail, limit=120.0):
     """runs native_node_child in a process of its own (a fault or a hang there must not take the headline with it)"""
     try:
         pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--native-node-child", str(ngpus), str(steps), str(warmup), str(detail)],

@@ -655,6 +655,8 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
             }
         }
     }
+    const char* const slotOrderEnv = getenv("MIPT_WIDE_SLOT_ORDER");  // read once, not once per wide node
+    const std::string slotOrder = slotOrderEnv ? slotOrderEnv : (d->n_lights > 0 ? "lightnear" : "big");
     std::priority_queue<std::pair<double, int>> open;
     open.push({boxArea(0), 0});
     while (!open.empty()) {
@@ -715,8 +717,7 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
             // box subtends at the light (58.1), by distance descending (69.9), by triangle count (66.4 / 56.4 ascending)
             // or leaving the tree's order (56.9) all lose to it.  A scene without lights keeps "big".
             // MIPT_WIDE_SLOT_ORDER = big | small | count | fewest | tree | treerev | lightnear | lightfar | lightangle.
-            const char* so = getenv("MIPT_WIDE_SLOT_ORDER");
-            const std::string mode = so ? so : (d->n_lights > 0 ? "lightnear" : "big");
+            const std::string& mode = slotOrder;
             if (mode == "big") std::stable_sort(sl, sl + ns, [&](int a, int b) { return boxArea(a) > boxArea(b); });
             else if (mode == "small") std::stable_sort(sl, sl + ns, [&](int a, int b) { return boxArea(a) < boxArea(b); });
             else if (mode == "count") std::stable_sort(sl, sl + ns, [&](int a, int b) { return triCount[a] > triCount[b]; });
