@@ -15,12 +15,18 @@ B = importlib.import_module("path-tracer_amd").binding
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
 bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
 total_bad = 0
-for name in ("cornellbox", "teapot-glass", "testObj", "bunny", "sponza"):
-    arrays = sf.sponza_standin(1) if name == "sponza" else sf.load_scene_arrays(name)
-    scene = sf.product_scene_from_mesh_arrays(*arrays)
-    orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+for name in ("cornellbox", "teapot-glass", "testObj", "bunny", "sponza", "room (5 objects)"):
+    if name.startswith("room"):  # several objects per scene (mipt_scene_create_multi), one of them twice: exact ties between objects
+        objs = sf.room_objects()
+        scene = sf.product_scene_from_objects(objs)
+        orc = sf.oracle_scene_from_objects(objs)
+        tri = np.concatenate([np.asarray(a[0], np.float32).reshape(-1, 3, 3) for a in objs])
+    else:
+        arrays = sf.sponza_standin(1) if name == "sponza" else sf.load_scene_arrays(name)
+        scene = sf.product_scene_from_mesh_arrays(*arrays)
+        orc = sf.oracle_scene_from_mesh_arrays(*arrays)
+        tri = np.asarray(arrays[0], np.float32).reshape(-1, 3, 3)
     ctx = B.Context(scene, device=0)
-    tri = np.asarray(arrays[0], np.float32).reshape(-1, 3, 3)
     lo, hi = tri.reshape(-1, 3).min(0), tri.reshape(-1, 3).max(0)
     rng = np.random.default_rng(hash(name) % 1000)
     def unit(v):
@@ -65,5 +71,5 @@ for name in ("cornellbox", "teapot-glass", "testObj", "bunny", "sponza"):
             bad[mname] = nb
         ctx.set_traversal(B.TRAVERSAL_DEFAULT)
         total_bad += sum(bad.values())
-        print(f"{name:13s} {label:40s} {N} rays  hits {int((ref[0] >= 0).sum()):8d}  mismatches {bad}  oracle threaded vs bit-trail: t differs {two_refs_t}, id differs {two_refs_id}  ({time.time() - t0:.1f} s)", flush=True)
+        print(f"{name:16s} {label:40s} {N} rays  hits {int((ref[0] >= 0).sum()):8d}  mismatches {bad}  oracle threaded vs bit-trail: t differs {two_refs_t}, id differs {two_refs_id}  ({time.time() - t0:.1f} s)", flush=True)
 print("TOTAL MISMATCHES", total_bad, flush=True)
