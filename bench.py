@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="serialise shadow-ray and extension-ray launches on one stream in the timed loop too (for rocprofv3 "
                          "--kernel-trace runs: overlapped kernels' begin-to-end times include waiting for CUs)")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N > 1: gather every step's tiles on the current stream (the next step waits for it) instead of on a side stream")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the per-step gather, barriers and reductions even with one "
                          "rank: the N > 1 code path on a one-GPU box (tests/test_gpu_node.py)")
@@ -249,6 +251,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist  # the collectives run
+    # stdout carries ONE line, the JSON: libraries that print there (RCCL's version banner when the first communicator
+    # is made) are sent to stderr for the rest of the run; the line itself goes to the kept descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if multi:
         if "MASTER_ADDR" not in os.environ:  # --force-dist typed without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
@@ -283,6 +290,7 @@ def main():
     gatherer = pkg.tiles.TileGather(W, H, rank, world, dev, TILE_W, TILE_H, always=args.force_dist)  # owned pixels -> rank 0, one RCCL gather per step
 
     def sync():
+        gatherer.finish()
         torch.cuda.synchronize(dev)
         if multi:
             dist.barrier()
@@ -298,7 +306,9 @@ def main():
             p = B.RenderParams(B.MODE_PATH, spp_per_step, state["sample"], BOUNCES, SEED, rank, world, TILE_W, TILE_H)
             ctx.render_device(cam, p, accum.data_ptr(), rgb.data_ptr())
             state["sample"] += spp_per_step
-            gatherer.gather(rgb)  # no-op on one GPU
+            # no-op on one GPU; else the owned tiles travel to rank 0 on a side stream beside the next step's kernels
+            # (--sync-gather: on the current stream, every step waiting for its gather as in round 2)
+            (gatherer.gather if args.sync_gather else gatherer.gather_async)(rgb)
 
         accum.zero_()
         ctx.set_overlap(not profile and not args.no_overlap)
@@ -448,7 +458,9 @@ def main():
                        "rays_per_step": total_rays / args.steps, "ms_per_frame_1spp": ms_frame,
                        "scene_create_s": t_scene,
                        "ms_per_step_serialised_with_events": serial_elapsed / args.steps * 1e3,
-                       "weak_scaling": weak, "native_node": native},
+                       "weak_scaling": weak, "native_node": native,
+                       "gather": None if not multi else ("current stream, every step waits for it" if args.sync_gather else
+                                                         "side stream beside the next step's kernels (TileGather.gather_async)")},
             "roofline": {"bound": "valu", "achieved": dom_ref["achieved_TFLOPs"], "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom_ref["achieved_TFLOPs"] / FP32_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": dom_name,
                          "flops_per_ray_reference_walk": dom_ref["algorithmic_flops_per_ray"],
@@ -515,7 +527,8 @@ def main():
                 out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(args.detail)
             except Exception as e:
                 out["cpu_baseline"]["all_cores"] = {"error": str(e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()

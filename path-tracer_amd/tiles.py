@@ -61,6 +61,47 @@ class TileGather:
                 m = self.idx[r].numel()
                 rgb3.index_copy_(0, self.idx[r], self.recv[r][: m * 3].view(-1, 3))
 
+    def gather_async(self, rgb_flat):
+        """gather() on a stream of its own, beside whatever the caller enqueues next on the current stream (the next
+        frame's kernels): the pack waits for the frame by an event, the collective and rank 0's unpack follow on the side
+        stream, and the current stream waits only for the pack (which reads rgb_flat) -- what mipt_node_render does with
+        its transfer stream (api_node.hip).  Rank 0's unpack writes the OTHER ranks' pixels of rgb_flat while the next
+        frame's kernels write rank 0's own: disjoint elements.  finish() (or a device-wide synchronize) before the frame is
+        read.  CPU tensors (gloo tests) take the synchronous path."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1 and not self.always:
+            return
+        if not rgb_flat.is_cuda:
+            return self.gather(rgb_flat)
+        dev = rgb_flat.device
+        cur = torch.cuda.current_stream(dev)
+        if getattr(self, "side", None) is None:
+            self.side = torch.cuda.Stream(device=dev)
+            self.ev_rendered = torch.cuda.Event()
+            self.ev_packed = torch.cuda.Event()
+        self.ev_rendered.record(cur)
+        rgb3 = rgb_flat.view(-1, 3)
+        n = self.idx[self.rank].numel()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_rendered)
+            # send / recv are touched on the side stream only, so successive steps are ordered there
+            self.send[: n * 3] = rgb3.index_select(0, self.idx[self.rank]).reshape(-1)
+            self.ev_packed.record(self.side)
+            work = dist.gather(self.send, self.recv, dst=0, async_op=True)
+            work.wait()  # the side stream (not the host) waits for the collective
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    m = self.idx[r].numel()
+                    rgb3.index_copy_(0, self.idx[r], self.recv[r][: m * 3].view(-1, 3))
+        cur.wait_event(self.ev_packed)  # the next frame may overwrite this rank's pixels once the pack has read them
+
+    def finish(self):
+        """the current stream waits for everything gather_async has enqueued"""
+        import torch
+        if getattr(self, "side", None) is not None:
+            torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+
     def gather_rgb8(self, rgb8_flat):
         """the same collective for a frame that has already been converted to 8 bits per channel on the device
         (Context.pack_rgb8_device: Image::save's conversion): rgb8_flat is this rank's frame as a flat uint8 tensor

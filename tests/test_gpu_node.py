@@ -114,10 +114,11 @@ def test_bench_rccl_path_with_one_rank(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--force-dist", "--native-node"], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), ("stdout must carry the JSON line and nothing else (RCCL's banner goes to stderr)", r.stdout[:400])
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 1000.0
+    assert "side stream" in out["config"]["gather"]  # the per-step gather runs beside the next step's kernels (TileGather.gather_async)
     weak = out["config"]["weak_scaling"]
     assert weak is not None and weak["spp_per_step"] == 16 and abs(weak["value"] / out["value"] - 1.0) < 0.1
     # ... and beside it the NATIVE node (mipt_node_render in a child process: one process, thread per GPU, RCCL), the
@@ -125,6 +126,37 @@ def test_bench_rccl_path_with_one_rank(tmp_path):
     nat = out["config"]["native_node"]
     assert nat is not None and "error" not in nat, nat
     assert nat["uses_rccl"] and nat["n_gpus"] == 1 and abs(nat["value"] / out["value"] - 1.0) < 0.15, nat
+
+
+def test_tile_gather_on_a_side_stream_leaves_the_frame_as_the_synchronous_one(tmp_path):
+    """TileGather.gather_async (bench.py's per-step gather for N > 1: pack behind an event, collective and unpack on a side
+    stream, the current stream waiting for the pack only) in a one-rank RCCL world, several steps in a row with work
+    enqueued behind each: the frame ends up as gather() leaves it.  In a process of its own (a process group per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "gather_async.py"
+    script.write_text(
+        "import importlib, os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "tiles = importlib.import_module('path-tracer_amd').tiles\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', RANK='0', WORLD_SIZE='1')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "w, h = 640, 360\n"
+        "g = tiles.TileGather(w, h, 0, 1, dev, always=True)\n"
+        "a = torch.arange(w * h * 3, dtype=torch.float32, device=dev)\n"
+        "b = a.clone()\n"
+        "for k in range(4):\n"
+        "    a += 1.0; b += 1.0\n"
+        "    g.gather_async(a)\n"
+        "    g.gather(b)\n"
+        "g.finish(); torch.cuda.synchronize()\n"
+        "assert torch.equal(a, b) and float(a[0]) == 4.0\n"
+        "dist.destroy_process_group()\n"
+        "print('gather ok')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and "gather ok" in r.stdout, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
