@@ -1021,6 +1021,8 @@ int ensure_slow(mipt_ctx* c, DevBuf& buf, int& parity, size_t capacity, hipStrea
     if (use) parity ^= 1;
     return MIPT_OK;
 }
+// the launch has emptied its own hand-back list (kernels_trace_wide.hip, "Draining the hand-back list"): no follow-up kernel
+inline bool drained_in_kernel(const mipt_ctx* c) { return PT_WIDE_DRAIN && c->ds.drain && c->ds.slowOk; }
 void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, unsigned* cursor, float4* hits) {
     if (!cursor) {
         cursor = (unsigned*)(c->dTotals + 6);
@@ -1033,8 +1035,10 @@ void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView 
         launch_trace_bittrail_closest(c->stream, c->ds, rays, index, q, hits, cnt);
     } else if (SlowView v{}; c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slow, c->slowParity, q.space, c->stream, v) == MIPT_OK) {
         launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, v.head, v.list, v.next);
-        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, v.list, v.head);  // short list: a wavefront per ray (else k_trace_wide's own wavefronts have done it)
-        launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, v.head + 1, hits, cnt, v.list, v.head);  // long list: a lane per ray
+        if (!drained_in_kernel(c)) {  // else k_trace_wide's own wavefronts have emptied the list, whatever its length
+            if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, v.list, v.head);  // short list: a wavefront per ray
+            launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, v.head + 1, hits, cnt, v.list, v.head);  // long list, deep tree: a lane per ray
+        }
     } else {
         launch_trace_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt);
     }
@@ -1055,8 +1059,10 @@ void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueVie
         launch_trace_bittrail_occluded(st, c->ds, rays, target, q, occ, cnt);
     } else if (SlowView v{}; c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slowOcc, c->slowOccParity, q.space, st, v) == MIPT_OK) {
         launch_trace_wide_occluded(st, c->ds, rays, target, q, cursor, occ, cnt, v.head, v.list, v.next);
-        if (!c->ds.drain) launch_trace_slow_occluded(st, c->ds, rays, target, occ, cnt, v.list, v.head);
-        launch_trace_occluded(st, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, v.head + 1, occ, cnt, v.list, v.head);
+        if (!drained_in_kernel(c)) {
+            if (!c->ds.drain) launch_trace_slow_occluded(st, c->ds, rays, target, occ, cnt, v.list, v.head);
+            launch_trace_occluded(st, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, v.head + 1, occ, cnt, v.list, v.head);
+        }
     } else {
         launch_trace_occluded(st, c->ds, rays, target, q, cursor, occ, cnt);
     }
@@ -1077,10 +1083,12 @@ bool trace_both(mipt_ctx* c, const float4* raysC, const int* indexC, QueueView q
     unsigned long long* cntO = c->counting ? c->dTotals + 4 : nullptr;
     launch_trace_wide_both(c->stream, c->ds, raysC, indexC, qC, cursorC, hits, cntC, vc.head, vc.list, raysO, targetO, qO, cursorO, occ,
                            cntO, vo.head, vo.list, c->shadowFirst ? 1 : 0, vc.next, vo.next);
-    if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, raysC, indexC, hits, cntC, vc.list, vc.head);
-    launch_trace_closest(c->stream, c->ds, raysC, indexC, QueueView{nullptr, 0u, qC.space}, vc.head + 1, hits, cntC, vc.list, vc.head);
-    if (!c->ds.drain) launch_trace_slow_occluded(c->stream, c->ds, raysO, targetO, occ, cntO, vo.list, vo.head);
-    launch_trace_occluded(c->stream, c->ds, raysO, targetO, QueueView{nullptr, 0u, qO.space}, vo.head + 1, occ, cntO, vo.list, vo.head);
+    if (!drained_in_kernel(c)) {
+        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, raysC, indexC, hits, cntC, vc.list, vc.head);
+        launch_trace_closest(c->stream, c->ds, raysC, indexC, QueueView{nullptr, 0u, qC.space}, vc.head + 1, hits, cntC, vc.list, vc.head);
+        if (!c->ds.drain) launch_trace_slow_occluded(c->stream, c->ds, raysO, targetO, occ, cntO, vo.list, vo.head);
+        launch_trace_occluded(c->stream, c->ds, raysO, targetO, QueueView{nullptr, 0u, qO.space}, vo.head + 1, occ, cntO, vo.list, vo.head);
+    }
     return true;
 #else
     return false;
@@ -1649,7 +1657,7 @@ int mipt_context_create(const mipt_scene* s, int device, void* stream, mipt_ctx*
     c->ds.nNodes = s->nNodes; c->ds.nLeafTris = s->nLeafTris; c->ds.nTris = s->nTris; c->ds.nMaterials = s->nMaterials;
     c->ds.envW = s->envW; c->ds.envH = s->envH; c->ds.nLights = s->nLights;
     c->ds.planesTame = s->planesTame ? 1 : 0;
-    c->ds.drain = 1;
+    c->ds.drain = PT_WIDE_DRAIN ? 1 : 0;
     if (const char* dv = getenv("MIPT_DRAIN")) c->ds.drain = std::string(dv) != "0" ? 1 : 0;  // A/B runs
     if (const char* hb = getenv("MIPT_HAND_BACK_ALL")) c->ds.handBackAll = std::string(hb) == "1" ? 1 : 0;  // tests: every ray through k_trace_slow / list-mode k_trace
     c->ds.nTopNodes = s->nTopNodes;
@@ -1889,7 +1897,7 @@ int mipt_trace_device_noalloc(mipt_ctx* c, const void* rays_dev, size_t n, void*
     if (n == 0) return MIPT_OK;
     if (!c->scratch) return fail(MIPT_ERR_DEVICE, "mipt_trace_device_noalloc: scratch not resolved on this device");
     HIP_TRY(hipSetDevice(c->device));
-    unsigned* head = (unsigned*)c->scratch;                 // [0] list count, [1] cursor of the list-mode launch
+    unsigned* head = (unsigned*)c->scratch;                 // [0] list count, [1] cursor of the list-mode launch, [2] blocks done, [3] claim cursor of the in-kernel drain
     unsigned* cursor = head + 32;                           // cursor of the main launch
     int* list = (int*)(c->scratch + kNoAllocHeaderBytes);   // queue slots of the handed-back rays, at most n
     HIP_TRY(hipMemsetAsync(head, 0, kNoAllocHeaderBytes, c->stream));  // the array keeps the last call's contents
@@ -1902,8 +1910,10 @@ int mipt_trace_device_noalloc(mipt_ctx* c, const void* rays_dev, size_t n, void*
         launch_trace_bittrail_closest(c->stream, c->ds, rays, nullptr, q, hits, cnt);
     } else if (c->ds.nWide > 0 && c->useWide) {
         launch_trace_wide_closest(c->stream, c->ds, rays, nullptr, q, cursor, hits, cnt, head, list);
-        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, nullptr, hits, cnt, list, head);
-        launch_trace_closest(c->stream, c->ds, rays, nullptr, QueueView{nullptr, 0u, q.space}, head + 1, hits, cnt, list, head);
+        if (!drained_in_kernel(c)) {
+            if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, nullptr, hits, cnt, list, head);
+            launch_trace_closest(c->stream, c->ds, rays, nullptr, QueueView{nullptr, 0u, q.space}, head + 1, hits, cnt, list, head);
+        }
     } else {
         launch_trace_closest(c->stream, c->ds, rays, nullptr, q, cursor, hits, cnt);
     }

@@ -267,9 +267,6 @@ constexpr unsigned kPendMask = 15u;
 #ifndef PT_WIDE_POOL
 #define PT_WIDE_POOL 1  // rays reach the wavefronts through a pool per BLOCK in LDS (below: "The block's pool"); 0: one chunk per wavefront from the global cursor
 #endif
-#ifndef PT_WIDE_DRAIN
-#define PT_WIDE_DRAIN 1  // the wavefronts that finish first trace the rays the launch has handed back ("Draining the hand-back list" in the body)
-#endif
 #ifndef PT_TUNE_WIDE_POOL_MIN
 #define PT_TUNE_WIDE_POOL_MIN 256u    // smallest / largest chunk a block asks the launch's cursor for
 #endif
@@ -1042,12 +1039,17 @@ __device__ __forceinline__ void wide_body(
 #if PT_WIDE_DRAIN
     // Draining the hand-back list (round 3).  The few rays a launch hands back (slowList: a zero direction component, a
     // failed verdict) used to wait for two more launches (k_trace_slow, list-mode k_trace), 20 to 35 us per traversal
-    // on the frame's critical path.  Now every wavefront that leaves the loop above looks at the list as it stands and
-    // traces what it can take -- an entry is taken by exchanging it with -1, the list's resting state -- with the whole
-    // wavefront per ray (slow_walk.hpp) on the LDS its lanes' stacks occupy; it then counts itself off, and the last
-    // wavefront of the last block, which by then can see every entry, looks once more.  Nobody waits for anybody, so
-    // blocks that are not resident yet cannot be waited for.  Lists longer than kSlowMaxRays and trees too deep for the
-    // stack stay with list-mode k_trace (a lane per ray), which skips what has been taken.
+    // on the frame's critical path.  Now every wavefront that leaves the loop above takes entries off the list as it
+    // stands and traces them with the whole wavefront per ray (slow_walk.hpp) on the LDS its lanes' stacks occupy; it
+    // then counts itself off, and the last wavefront of the last block, which by then sees the final count, takes what
+    // is left.  Entries are CLAIMED through a cursor (header word 3: a compare-and-swap moves it from h to h + batch, never
+    // beyond the count as it stands, so no index is claimed that may never be filled); a claimed entry may be a moment
+    // behind its count -- its producer, a running wavefront that waits for nobody, has incremented the count and is about
+    // to store the entry -- so the claimant reads it until it is there, and puts -1 back: the list rests at -1 for the
+    // next launch.  Nobody waits for anything but such a store in flight, so blocks that are not resident yet cannot be
+    // waited for, and a list of ANY length is emptied here (batches grow with the list: one entry per claim for the
+    // usual few dozen rays, up to 64 for a list of millions): no follow-up launch.  Trees too deep for the stack
+    // (!slowOk) keep list-mode k_trace, a lane per ray, in a launch of its own.
     // (Visibility without fences: an agent-scope fence writes the whole L2 of the wavefront's XCD back -- 4,096 of them cost
     // 160 us per launch when tried.  The list is therefore written, read and taken with agent-scope ATOMICS only, which
     // act at the memory side and need no cache maintenance, and a wavefront waits for its own outstanding memory
@@ -1057,38 +1059,46 @@ __device__ __forceinline__ void wide_body(
         __builtin_amdgcn_s_waitcnt(0);  // this wavefront's own entries are out before it is counted off
         int* const wstack = (int*)stackLds + waveBase;
         for (int pass = 0; pass < 2; pass++) {
-            unsigned n = 0;
-            if (lane == 0) n = __hip_atomic_load(slowCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            n = (unsigned)__builtin_amdgcn_readfirstlane((int)n);
-            if (n != 0u && n <= kSlowMaxRays) {
-                for (unsigned base = 0; base < n; base += 64u) {
-                    int e = -1;
-                    if (base + (unsigned)lane < n) e = __hip_atomic_load(&slowList[base + (unsigned)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    unsigned long long m = __ballot(e >= 0);
-                    while (m != 0ull) {
-                        const int j = __builtin_ctzll(m);
-                        m &= m - 1ull;
-                        int got = -1;
-                        if (lane == 0) got = atomicExch(&slowList[base + (unsigned)j], -1);
-                        got = __builtin_amdgcn_readfirstlane(got);
-                        if (got < 0) continue;  // another wavefront was faster
-                        const unsigned slot = (unsigned)got;
-                        const unsigned rsl = index ? (unsigned)index[slot] : slot;
-                        const size_t rs = ANYHIT ? (size_t)slot : (size_t)rsl;
-                        const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
-                        int bTri, bSeq;
-                        float bT, bB, bG;
-                        slow_walk_wave<ANYHIT, COUNT, kBlk>(s, vec3{r0.x, r0.y, r0.z}, vec3{r1.x, r1.y, r1.z}, r0.w, r1.w, wstack,
-                                                            64 * kWideMaxDepth, lane, bTri, bSeq, bT, bB, bG, nv, nt);
-                        if (lane == 0) {
-                            if (ANYHIT) {
-                                if (bTri >= 0) occ[target ? (unsigned)target[slot] : slot] = 1;
-                            } else {
-                                hits[rsl] = make_float4(i2f(bTri), bT, bB, bG);
-                            }
-                        }
-                        wave_lds_sync();
+            for (;;) {
+                unsigned k = 0u, k2 = 0u;
+                if (lane == 0) {
+                    const unsigned n = __hip_atomic_load(slowCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned h = __hip_atomic_load(&slowCount[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (h < n) {
+                        unsigned batch = (n - h) / (2u * nWaves);
+                        batch = batch < 1u ? 1u : (batch > 64u ? 64u : batch);
+                        const unsigned want = (n - h) < batch ? n : h + batch;
+                        const unsigned old = atomicCAS(&slowCount[3], h, want);
+                        if (old == h) { k = h; k2 = want; break; }
+                        h = old;
                     }
+                }
+                k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+                k2 = (unsigned)__builtin_amdgcn_readfirstlane((int)k2);
+                if (k2 == k) break;  // nothing below the count that is not somebody's already
+                for (unsigned i = k; i < k2; i++) {
+                    int got = -1;
+                    if (lane == 0) {
+                        do got = __hip_atomic_load(&slowList[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); while (got < 0);
+                        __hip_atomic_store(&slowList[i], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    got = __builtin_amdgcn_readfirstlane(got);
+                    const unsigned slot = (unsigned)got;
+                    const unsigned rsl = index ? (unsigned)index[slot] : slot;
+                    const size_t rs = ANYHIT ? (size_t)slot : (size_t)rsl;
+                    const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
+                    int bTri, bSeq;
+                    float bT, bB, bG;
+                    slow_walk_wave<ANYHIT, COUNT, kBlk>(s, vec3{r0.x, r0.y, r0.z}, vec3{r1.x, r1.y, r1.z}, r0.w, r1.w, wstack,
+                                                        64 * kWideMaxDepth, lane, bTri, bSeq, bT, bB, bG, nv, nt);
+                    if (lane == 0) {
+                        if (ANYHIT) {
+                            if (bTri >= 0) occ[target ? (unsigned)target[slot] : slot] = 1;
+                        } else {
+                            hits[rsl] = make_float4(i2f(bTri), bT, bB, bG);
+                        }
+                    }
+                    wave_lds_sync();
                 }
             }
             if (pass == 1) break;
