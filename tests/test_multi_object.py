@@ -175,3 +175,42 @@ def test_headless_cli_adds_objects(B, tmp_path):
     alone = B.Context(B.Scene(B.Mesh.load(str(a))), device=0).render(cam, mode=B.MODE_DIRECT)
     assert np.array_equal(bits(img), bits(both))
     assert not np.array_equal(bits(img), bits(alone))
+
+
+def _check_against_room_golden(g, label, tri, t, bary, occ, ob):
+    hit = tri >= 0
+    assert int(hit.sum()) == int(g[f"{label}_hits"])
+    assert ob.fnv1a32_of_bits(bits(t[hit])) == int(g[f"{label}_fnv_t"])
+    assert ob.fnv1a32_of_bits(bits(tri)) == int(g[f"{label}_fnv_tri"])
+    assert ob.fnv1a32_of_bits(bits(bary[hit]).reshape(-1)) == int(g[f"{label}_fnv_bary"])
+    s = int(g["stride"])
+    assert np.array_equal(tri[::s], g[f"{label}_sub_tri"]) and np.array_equal(bits(t[::s]), bits(g[f"{label}_sub_t"]))
+    assert np.array_equal(bits(bary[::s]), bits(g[f"{label}_sub_bary"]))
+    base = g["tri_base"]
+    per_object = [int(((tri >= base[k]) & (tri < base[k + 1])).sum()) for k in range(len(base) - 1)]
+    assert per_object == g[f"{label}_hits_per_object"].tolist() and per_object[3] == 0
+    assert int(occ.sum()) == int(g[f"{label}_occluded"]) and ob.fnv1a32_of_bits(occ.astype(np.uint32)) == int(g[f"{label}_fnv_occ"])
+
+
+def test_oracle_against_the_committed_records_of_the_room(ob, sf):
+    """tests/golden/golden_room.npz (make_room_golden.py): the oracle's scene of several objects keeps returning what it
+    returned when the fixture was made, for both of the reference's traversals"""
+    g = np.load(os.path.join(sf.GOLDEN, "golden_room.npz"))
+    orc = room(sf, False)
+    o, d = orc.eye_rays(ob.make_camera(int(g["width"]), int(g["height"])))
+    for label, variant in (("threaded", ob.THREADED), ("bittrail", ob.BITTRAIL)):
+        tri, t, bary = orc.intersect(o, d, variant=variant)
+        _check_against_room_golden(g, label, tri, t, bary, orc.occluded(o, d, 0.0, 1.4, variant=variant), ob)
+
+
+@pytest.mark.gpu
+def test_product_against_the_committed_records_of_the_room(B, ob, sf):
+    """the same committed records through the C-ABI: the default traversal and the literal walk against the threaded
+    records, the bit-trail kernel against the bit-trail records"""
+    g = np.load(os.path.join(sf.GOLDEN, "golden_room.npz"))
+    ctx = B.Context(room(sf, True), device=0)
+    o, d = ctx.eye_rays(B.default_camera(int(g["width"]), int(g["height"])))
+    for label, mode in (("threaded", B.TRAVERSAL_DEFAULT), ("threaded", B.TRAVERSAL_THREADED), ("bittrail", B.TRAVERSAL_BITTRAIL)):
+        ctx.set_traversal(mode)
+        tri, t, bary = ctx.trace(o, d)
+        _check_against_room_golden(g, label, tri, t, bary, ctx.occluded(o, d, 0.0, 1.4), ob)
