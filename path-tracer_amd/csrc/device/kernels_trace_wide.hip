@@ -1079,10 +1079,17 @@ __device__ __forceinline__ void wide_body(
                 for (unsigned i = k; i < k2; i++) {
                     int got = -1;
                     if (lane == 0) {
-                        do got = __hip_atomic_load(&slowList[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); while (got < 0);
-                        __hip_atomic_store(&slowList[i], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // (bounded: a store in flight arrives within microseconds; the bound only keeps a wavefront from
+                        // spinning for ever should an entry never come -- every wavefront must reach its end)
+                        for (int spin = 0; spin < (1 << 20); spin++) {
+                            got = __hip_atomic_load(&slowList[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (got >= 0) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (got >= 0) __hip_atomic_store(&slowList[i], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     got = __builtin_amdgcn_readfirstlane(got);
+                    if (got < 0) continue;
                     const unsigned slot = (unsigned)got;
                     const unsigned rsl = index ? (unsigned)index[slot] : slot;
                     const size_t rs = ANYHIT ? (size_t)slot : (size_t)rsl;
