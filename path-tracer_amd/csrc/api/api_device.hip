@@ -831,6 +831,11 @@ static bool build_wide(const mipt_scene_desc* d, mipt_scene* s, const int collap
                 if (!(half_value(h[k]) <= lo[a][k]) || !(half_value(h[K + k]) >= hi[a][k]) || (h[k] & 0x7fffu) >= 0x7c00u ||
                     (h[K + k] & 0x7fffu) >= 0x7c00u)
                     return false;  // a plane beyond the fp16 range: this scene takes the literal walk
+                // An EMPTY slot of an eight-slot node holds the box no ray can hit: lo = +inf, hi = -inf on every axis.  Whatever
+                // the ray (its reciprocals are finite and nonzero, its constants finite: fast_div_ok), the near quotient
+                // comes out +inf and the far one -inf, so the slot test rejects it without a mask of the used slots
+                // (kernels_trace_wide.hip keeps only the count of interior slots).  Four-slot nodes keep slot 0's box and their masks.
+                if (K == 8 && sl[k] < 0) { h[k] = 0x7c00u; h[K + k] = 0xfc00u; }
             }
             memcpy((char*)rec + 4 * K * a, h, 4 * K);
         }
@@ -1116,7 +1121,7 @@ int make_camera(const mipt_camera* cam, CameraDev& out) {
 // build's switches; the file holds its output under a 64-bit FNV-1a key over exactly those, and is used only when the key,
 // the layout constants and its own checksum all agree.  Written to a temporary name and renamed, so that ranks racing
 // for one path read either nothing or a whole file.
-constexpr unsigned kWideCacheVersion = 3;
+constexpr unsigned kWideCacheVersion = 4;  // 4: empty slots of an eight-slot node hold the box no ray hits (lo = +inf, hi = -inf)
 struct Fnv {
     unsigned long long h = 1469598103934665603ull;
     void add(const void* p, size_t n) {

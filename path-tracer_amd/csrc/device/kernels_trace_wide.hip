@@ -201,6 +201,9 @@ __device__ __forceinline__ int wide_hit_mask_fma(const float4v nearx, const floa
 #undef PT_F
     return (!(u0 > v0) ? 1 : 0) | (!(u1 > v1) ? 2 : 0) | (!(u2 > v2) ? 4 : 0) | (!(u3 > v3) ? 8 : 0);
 }
+#ifndef PT_TUNE_WIDE_SIGNMASK
+#define PT_TUNE_WIDE_SIGNMASK 1  // the slot test's hit mask from the sign bits of v - u (wide_hit_mask_fma_h)
+#endif
 #if PT_WIDE_HALF
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
@@ -223,7 +226,19 @@ __device__ __forceinline__ int wide_hit_mask_fma_h(const half4v nearx, const hal
     const float u3 = fmaxf(fmaxf(fmaxf(PT_F(nearx.w, ynx, cnx), PT_F(neary.w, yny, cny)), PT_F(nearz.w, ynz, cnz)), 0.0f);
     const float v3 = fminf(fminf(PT_F(farx.w, yfx, cfx), PT_F(fary.w, yfy, cfy)), PT_F(farz.w, yfz, cfz));
 #undef PT_F
+#if PT_TUNE_WIDE_SIGNMASK
+    // slot k is missed iff u_k > v_k iff the float v_k - u_k is negative (a difference of two finite floats has the sign
+    // of the exact difference, and is -0 never: x - x = +0; every t here is finite, see fast_div_ok): its sign bit goes
+    // straight into the mask -- v_sub_f32 + v_alignbit_b32 (m << 1 | sign) per slot instead of a compare into vcc, a
+    // select on vcc and an or
+    unsigned m = __builtin_amdgcn_alignbit(0u, (unsigned)f2i(v3 - u3), 31u);
+    m = __builtin_amdgcn_alignbit(m, (unsigned)f2i(v2 - u2), 31u);
+    m = __builtin_amdgcn_alignbit(m, (unsigned)f2i(v1 - u1), 31u);
+    m = __builtin_amdgcn_alignbit(m, (unsigned)f2i(v0 - u0), 31u);
+    return (int)(~m & 15u);
+#else
     return (!(u0 > v0) ? 1 : 0) | (!(u1 > v1) ? 2 : 0) | (!(u2 > v2) ? 4 : 0) | (!(u3 > v3) ? 8 : 0);
+#endif
 }
 // fp16 planes back to the scene's scale (k = DevScene::wideInvScale, a power of two: exact)
 __device__ __forceinline__ float4v widen(const half4v h, const float k) { return float4v{(float)h.x * k, (float)h.y * k, (float)h.z * k, (float)h.w * k}; }
@@ -773,10 +788,10 @@ __device__ __forceinline__ void wide_body(
                 }
 #undef PT_PIECE
                 const int counts = f2i(meta.z);
-                const int nInt = counts & 255, nLeafSlots = counts >> 8;
-                const int imask = (1 << nInt) - 1, lmask = ((1 << nLeafSlots) - 1) << nInt;
+                const int nInt = counts & 255;  // interior slots come first, then the leaf slots; the EMPTY slots behind them hold
+                                                // the box no ray hits (+inf / -inf planes, build_wide), so no mask of the used slots
 #if !PT_DIAG_UTIL
-                if (COUNT) nv += (unsigned)(nInt + nLeafSlots);
+                if (COUNT) nv += (unsigned)(nInt + (counts >> 8));
 #endif
                 int hm;
                 if (precise)
@@ -789,11 +804,11 @@ __device__ __forceinline__ void wide_body(
                                              cfx, cfy, cfz) |
                          (wide_hit_mask_fma_h(nx8.hi, fx8.hi, ny8.hi, fy8.hi, nz8.hi, fz8.hi, ynx, yny, ynz, yfx, yfy, yfz, cnx, cny,
                                               cnz, cfx, cfy, cfz) << 4);
-                const int lh = hm & lmask, ih = hm & imask;
+                const int lh = hm >> nInt, ih = hm & ((1 << nInt) - 1);  // lh: bit k = leaf slot k of this node
                 if (lh != 0) {  // park the candidate leaves of this node as one group
 #pragma unroll
                     for (int k = kWideGroups - 1; k > 0; k--) g[k] = g[k - 1];
-                    g[0] = ((unsigned)f2i(meta.y) << 8) | (unsigned)(lh >> nInt);
+                    g[0] = ((unsigned)f2i(meta.y) << 8) | (unsigned)lh;
                     ++groups;
                 }
                 if (ih != 0) {  // the hit children go on top of the stack as one entry
