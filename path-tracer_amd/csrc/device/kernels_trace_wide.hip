@@ -183,7 +183,7 @@ __device__ __forceinline__ int wide_hit_mask(const float4v nearx, const float4v 
 // The price is a slack of up to 7 u |o| in SPACE along each axis, i.e. 7 u |o y| in t: harmless while |y| is moderate,
 // but a ray with a tiny direction component (huge y) that starts ON a box plane -- every secondary ray starts on a
 // wall -- would then pass every box that touches that plane within a long stretch of t.  Such rays (a direction
-// component below 2^-12, 7 in 10,000) keep the subtract-and-multiply form: `precise` lanes, same kernel.
+// component below 2^-16, 0.5 in 10,000; round 2: 2^-12) keep the subtract-and-multiply form: `precise` lanes, same kernel.
 __device__ __forceinline__ int wide_hit_mask_fma(const float4v nearx, const float4v farx, const float4v neary, const float4v fary,
                                                  const float4v nearz, const float4v farz, const float ynx, const float yny,
                                                  const float ynz, const float yfx, const float yfy, const float yfz,
@@ -201,6 +201,9 @@ __device__ __forceinline__ int wide_hit_mask_fma(const float4v nearx, const floa
 #undef PT_F
     return (!(u0 > v0) ? 1 : 0) | (!(u1 > v1) ? 2 : 0) | (!(u2 > v2) ? 4 : 0) | (!(u3 > v3) ? 8 : 0);
 }
+#ifndef PT_TUNE_WIDE_PRECISE_EXP
+#define PT_TUNE_WIDE_PRECISE_EXP (-16)  // rays with a direction component below 2^this keep the subtract-and-multiply slot test (`precise` lanes).  A wavefront that holds one runs BOTH forms on every visit: r3, ms per closest-hit bench launch: -10: 4.16, -12: 4.05, -14 .. -20: 4.02, -24: 4.03
+#endif
 #ifndef PT_TUNE_WIDE_SIGNMASK
 #define PT_TUNE_WIDE_SIGNMASK 1  // the slot test's hit mask from the sign bits of v - u (wide_hit_mask_fma_h)
 #endif
@@ -703,7 +706,7 @@ __device__ __forceinline__ void wide_body(
                             cfx = __builtin_fmaf(__builtin_fabsf(bx), -0x1p-22f, bx); cfy = __builtin_fmaf(__builtin_fabsf(by), -0x1p-22f, by);
                             cfz = __builtin_fmaf(__builtin_fabsf(bz), -0x1p-22f, bz);
                         }
-                        precise = !(mag_within(dx, -12, kDirHi) && mag_within(dy, -12, kDirHi) && mag_within(dz, -12, kDirHi));
+                        precise = !(mag_within(dx, PT_TUNE_WIDE_PRECISE_EXP, kDirHi) && mag_within(dy, PT_TUNE_WIDE_PRECISE_EXP, kDirHi) && mag_within(dz, PT_TUNE_WIDE_PRECISE_EXP, kDirHi));
 #if PT_WIDE_HALF
                         // the stored planes are p S with S a power of two (DevScene::wideInvScale = 1 / S): p S (y' / S) is the
                         // same real product, and y' / S is exact, so the fma form sees no difference; the constants c were
