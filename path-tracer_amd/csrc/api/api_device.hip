@@ -1026,8 +1026,11 @@ int ensure_slow(mipt_ctx* c, DevBuf& buf, int& parity, size_t capacity, hipStrea
     if (use) parity ^= 1;
     return MIPT_OK;
 }
-// the launch has emptied its own hand-back list (kernels_trace_wide.hip, "Draining the hand-back list"): no follow-up kernel
-inline bool drained_in_kernel(const mipt_ctx* c) { return PT_WIDE_DRAIN && c->ds.drain && c->ds.slowOk; }
+// k_trace_wide empties SHORT hand-back lists itself (kernels_trace_wide.hip, "Draining the hand-back list"); what it leaves -- a
+// long list, a tree too deep for its exact walk -- is looked after by list-mode k_trace, which returns at once when nothing
+// is left.  (A launch that emptied lists of any length through a claim cursor, and no follow-up, was tried: 1,500 entries
+// took 23 ms.)  The short-list kernel k_trace_slow runs only when the in-kernel drain is off.
+inline bool drained_in_kernel(const mipt_ctx*) { return false; }
 void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, unsigned* cursor, float4* hits) {
     if (!cursor) {
         cursor = (unsigned*)(c->dTotals + 6);
@@ -1902,7 +1905,7 @@ int mipt_trace_device_noalloc(mipt_ctx* c, const void* rays_dev, size_t n, void*
     if (n == 0) return MIPT_OK;
     if (!c->scratch) return fail(MIPT_ERR_DEVICE, "mipt_trace_device_noalloc: scratch not resolved on this device");
     HIP_TRY(hipSetDevice(c->device));
-    unsigned* head = (unsigned*)c->scratch;                 // [0] list count, [1] cursor of the list-mode launch, [2] blocks done, [3] claim cursor of the in-kernel drain
+    unsigned* head = (unsigned*)c->scratch;                 // [0] list count, [1] cursor of the list-mode launch, [2] blocks done, [3] complement of the least count a draining wavefront saw
     unsigned* cursor = head + 32;                           // cursor of the main launch
     int* list = (int*)(c->scratch + kNoAllocHeaderBytes);   // queue slots of the handed-back rays, at most n
     HIP_TRY(hipMemsetAsync(head, 0, kNoAllocHeaderBytes, c->stream));  // the array keeps the last call's contents

@@ -85,9 +85,9 @@ __global__ __launch_bounds__(kTraceBlock) PT_TRACE_ATTR void k_trace(DevScene s,
                                                   unsigned long long* __restrict__ counters,
                                                   int* __restrict__ remap, const unsigned* __restrict__ remapCount) {
     // remap != nullptr: the queue is the list remap[0 .. *remapCount) of queue slots (the rays k_trace_wide handed
-    // back, kernels_trace_wide.hip); most launches find it empty
-    // (short lists belong to k_trace_slow below: a wavefront per ray instead of a lane per ray)
-    if (remap && ((*remapCount <= kSlowMaxRays && s.slowOk) || (size_t)blockIdx.x * kTraceBlock >= (size_t)*remapCount)) return;  // a block per kTraceBlock listed rays is plenty
+    // back, kernels_trace_wide.hip); most launches find it empty, or find every entry taken (-1: k_trace_wide's own
+    // wavefronts empty short lists, and with MIPT_DRAIN=0 k_trace_slow below does) -- what is left is traced here, a lane per ray
+    if (remap && (size_t)blockIdx.x * kTraceBlock >= (size_t)*remapCount) return;  // a block per kTraceBlock listed rays is plenty
     __shared__ float4 top[2 * kTopNodes];
     __shared__ unsigned prefix[kShards + 1];
     const int lane = threadIdx.x & 63;

@@ -202,7 +202,13 @@ __device__ __forceinline__ int wide_hit_mask_fma(const float4v nearx, const floa
     return (!(u0 > v0) ? 1 : 0) | (!(u1 > v1) ? 2 : 0) | (!(u2 > v2) ? 4 : 0) | (!(u3 > v3) ? 8 : 0);
 }
 #ifndef PT_TUNE_WIDE_PRECISE_EXP
-#define PT_TUNE_WIDE_PRECISE_EXP (-16)  // rays with a direction component below 2^this keep the subtract-and-multiply slot test (`precise` lanes).  A wavefront that holds one runs BOTH forms on every visit: r3, ms per closest-hit bench launch: -10: 4.16, -12: 4.05, -14 .. -20: 4.02, -24: 4.03
+#define PT_TUNE_WIDE_PRECISE_EXP (-20)  // rays with a direction component below 2^this do not take the one-fma slot test (its slack is absolute: such a ray passes every box that touches its start plane): they are handed to the exact walk, or, with PT_TUNE_WIDE_PRECISE_HANDBACK=0, keep the subtract-and-multiply form as `precise` lanes (a wavefront that holds one then runs BOTH forms on every visit: r3, ms per closest-hit bench launch: -10: 4.16, -12: 4.05, -14 .. -20: 4.02, -24: 4.03)
+#endif
+#ifndef PT_TUNE_WIDE_PRECISE_HANDBACK
+#define PT_TUNE_WIDE_PRECISE_HANDBACK 1  // 1: rays with a direction component below 2^PT_TUNE_WIDE_PRECISE_EXP are handed to the exact walk (a few dozen per launch, traced by the wavefronts that finish first) and the kernel has no subtract-and-multiply slot test: 128 -> 108 VGPRs (closest hit), 110 -> 88 (any hit).  0: they stay, as `precise` lanes
+#endif
+#ifndef PT_TUNE_WIDE_CARRY_ID
+#define PT_TUNE_WIDE_CARRY_ID 1  // 1: the winning triangle's id is carried in a register (there is room since the `precise` form left); 0: looked up in leafTris when the ray finishes, a dependent load every wavefront waited for after nearly every burst
 #endif
 #ifndef PT_TUNE_WIDE_SIGNMASK
 #define PT_TUNE_WIDE_SIGNMASK 1  // the slot test's hit mask from the sign bits of v - u (wide_hit_mask_fma_h)
@@ -374,6 +380,7 @@ __device__ __forceinline__ void wide_prefix(const QueueView& q, unsigned* prefix
         poolCtl[0] = 0u;
         poolCtl[1] = (unsigned long long)gridDim.x * C0 >= (unsigned long long)total ? 1u : 0u;  // nothing behind the static chunks
         poolCtl[2] = 0u;
+        poolCtl[3] = 0xffffffffu;  // the least list count a draining wavefront of this block has seen
     }
 }
 
@@ -511,7 +518,8 @@ __device__ __forceinline__ void wide_body(
             /* the id of the winning triangle sits in its leafTris record; looking it up here, once per ray, */ \
             /* keeps it out of the leaf loop's registers */                               \
             int id = -1;                                                                   \
-            if (bestSeq != 0x7fffffff) id = f2i(s.leafTris[3 * (size_t)bestSeq].w);        \
+            if (PT_TUNE_WIDE_CARRY_ID) { if (bestSeq != 0x7fffffff) id = bestTri; }        \
+            else if (bestSeq != 0x7fffffff) id = f2i(s.leafTris[3 * (size_t)bestSeq].w);   \
             hits[raySlot] = make_float4(i2f(id), bestT, bestB, bestG);                     \
         }                                                                                  \
         PT_RESET_LANE();                                                                   \
@@ -694,7 +702,11 @@ __device__ __forceinline__ void wide_body(
                     ox = r0.x; oy = r0.y; oz = r0.z; tMin = r0.w;
                     dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
                     // (an adopted ray qualified when its owner took it from the queue)
-                    if (adopt || (!s.handBackAll && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz}))) {
+                    if (adopt || (!s.handBackAll && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz})
+#if PT_TUNE_WIDE_PRECISE_HANDBACK
+                                  && mag_within(dx, PT_TUNE_WIDE_PRECISE_EXP, kDirHi) && mag_within(dy, PT_TUNE_WIDE_PRECISE_EXP, kDirHi) && mag_within(dz, PT_TUNE_WIDE_PRECISE_EXP, kDirHi)
+#endif
+                                  )) {
                         yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
 #if PT_TUNE_WIDE_FMA
                         ynx = yx * 0x1.ffffcp-1f; yny = yy * 0x1.ffffcp-1f; ynz = yz * 0x1.ffffcp-1f;
@@ -706,7 +718,11 @@ __device__ __forceinline__ void wide_body(
                             cfx = __builtin_fmaf(__builtin_fabsf(bx), -0x1p-22f, bx); cfy = __builtin_fmaf(__builtin_fabsf(by), -0x1p-22f, by);
                             cfz = __builtin_fmaf(__builtin_fabsf(bz), -0x1p-22f, bz);
                         }
+#if PT_TUNE_WIDE_PRECISE_HANDBACK
+                        precise = false;
+#else
                         precise = !(mag_within(dx, PT_TUNE_WIDE_PRECISE_EXP, kDirHi) && mag_within(dy, PT_TUNE_WIDE_PRECISE_EXP, kDirHi) && mag_within(dz, PT_TUNE_WIDE_PRECISE_EXP, kDirHi));
+#endif
 #if PT_WIDE_HALF
                         // the stored planes are p S with S a power of two (DevScene::wideInvScale = 1 / S): p S (y' / S) is the
                         // same real product, and y' / S is exact, so the fma form sees no difference; the constants c were
@@ -797,7 +813,7 @@ __device__ __forceinline__ void wide_body(
                 if (COUNT) nv += (unsigned)(nInt + (counts >> 8));
 #endif
                 int hm;
-                if (precise)
+                if (!PT_TUNE_WIDE_PRECISE_HANDBACK && precise)
                     hm = wide_hit_mask_sub(widen(nx8.lo, s.wideInvScale), widen(fx8.lo, s.wideInvScale), widen(ny8.lo, s.wideInvScale), widen(fy8.lo, s.wideInvScale), widen(nz8.lo, s.wideInvScale), widen(fz8.lo, s.wideInvScale),
                                            ox, oy, oz, ynx, yny, ynz, yfx, yfy, yfz) |
                          (wide_hit_mask_sub(widen(nx8.hi, s.wideInvScale), widen(fx8.hi, s.wideInvScale), widen(ny8.hi, s.wideInvScale), widen(fy8.hi, s.wideInvScale), widen(nz8.hi, s.wideInvScale), widen(fz8.hi, s.wideInvScale),
@@ -970,7 +986,7 @@ __device__ __forceinline__ void wide_body(
                     if (acc) {  // provisionally the best; its leaf's exact box is tested at the end of this leaf phase
                         // a verified best that an unverified one replaces is lost if the latter fails: that ray is
                         // re-traced (see above), so nothing needs to be kept
-                        if (ANYHIT) bestTri = f2i(q0.w);  // any hit: the flag "something accepted"; closest hit: see PT_FINISH
+                        if (ANYHIT || PT_TUNE_WIDE_CARRY_ID) bestTri = f2i(q0.w);  // any hit: the flag "something accepted"; closest hit: see PT_FINISH
                         bestSeq = cur; bestT = t; bestB = be; bestG = ga;
                         uLeaf = curLeaf;
                     }
@@ -1043,6 +1059,7 @@ __device__ __forceinline__ void wide_body(
                             (void)tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z}, vec3{ox, oy, oz},
                                            vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
                             bestT = t; bestB = be; bestG = ga;
+                            if (PT_TUNE_WIDE_CARRY_ID) bestTri = f2i(q0.w);
                         }
                         PT_FINISH();
                     }
@@ -1057,83 +1074,110 @@ __device__ __forceinline__ void wide_body(
 #if PT_WIDE_DRAIN
     // Draining the hand-back list (round 3).  The few rays a launch hands back (slowList: a zero direction component, a
     // failed verdict) used to wait for two more launches (k_trace_slow, list-mode k_trace), 20 to 35 us per traversal
-    // on the frame's critical path.  Now every wavefront that leaves the loop above takes entries off the list as it
-    // stands and traces them with the whole wavefront per ray (slow_walk.hpp) on the LDS its lanes' stacks occupy; it
-    // then counts itself off, and the last wavefront of the last block, which by then sees the final count, takes what
-    // is left.  Entries are CLAIMED through a cursor (header word 3: a compare-and-swap moves it from h to h + batch, never
-    // beyond the count as it stands, so no index is claimed that may never be filled); a claimed entry may be a moment
-    // behind its count -- its producer, a running wavefront that waits for nobody, has incremented the count and is about
-    // to store the entry -- so the claimant reads it until it is there, and puts -1 back: the list rests at -1 for the
-    // next launch.  Nobody waits for anything but such a store in flight, so blocks that are not resident yet cannot be
-    // waited for, and a list of ANY length is emptied here (batches grow with the list: one entry per claim for the
-    // usual few dozen rays, up to 64 for a list of millions): no follow-up launch.  Trees too deep for the stack
-    // (!slowOk) keep list-mode k_trace, a lane per ray, in a launch of its own.
+    // on the frame's critical path.  Now every wavefront that leaves the loop above traces its share of the list as it
+    // stands, the whole wavefront per ray (slow_walk.hpp) on the LDS its lanes' stacks occupy: entry i belongs to wavefront
+    // i mod nWaves -- no claiming, hence no atomics that thousands of wavefronts would fight over.  (Two claiming schemes
+    // were tried first.  Scan the list and take entries by exchange: every wavefront that arrives walks over the entries
+    // the earlier ones took.  A compare-and-swap cursor: all wavefronts arrive at once, one wins per round, and a list
+    // of 1,500 entries took 23 ms.)  The owner puts -1 back, the list's resting state, BEFORE it traces the ray.  An entry
+    // may be a moment behind its count -- its producer, a running wavefront that waits for nobody, is between its
+    // atomicAdd and its store -- so the owner reads it until it is there (bounded).  A wavefront then records how much of
+    // the list it has seen (header word 3 keeps the complement of the minimum) and counts itself off; entries that arrive
+    // after their owner has gone are orphans, all of them at or above that minimum, and the last wavefront of the last
+    // block -- which sees the final count, and runs when every owner has finished -- traces those.  Nobody waits for
+    // anything but a store in flight, so blocks that are not resident yet cannot be waited for.
+    // Only SHORT lists are emptied here: up to two entries per wavefront of the launch (the usual few dozen rays of a frame;
+    // all of a launch's rays when they are few).  A longer list -- a batch of axis-parallel rays, say, none of which
+    // qualifies -- is work for every LANE, not for a wavefront per ray, and wavefronts that leave early would orphan most
+    // of it: it is left as it stands (what was taken reads -1) for the launch that follows, list-mode k_trace, which
+    // skips what has been taken; the same launch looks after trees too deep for this walk's stack (!slowOk).
     // (Visibility without fences: an agent-scope fence writes the whole L2 of the wavefront's XCD back -- 4,096 of them cost
-    // 160 us per launch when tried.  The list is therefore written, read and taken with agent-scope ATOMICS only, which
+    // 160 us per launch when tried.  The list is therefore written, read and reset with agent-scope ATOMICS only, which
     // act at the memory side and need no cache maintenance, and a wavefront waits for its own outstanding memory
     // operations (s_waitcnt) before it counts itself off, so that its entries are there when the count says so.)
     if (s.drain && s.slowOk) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);  // this wavefront's own entries are out before it is counted off
         int* const wstack = (int*)stackLds + waveBase;
-        for (int pass = 0; pass < 2; pass++) {
-            for (;;) {
-                unsigned k = 0u, k2 = 0u;
-                if (lane == 0) {
-                    const unsigned n = __hip_atomic_load(slowCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    unsigned h = __hip_atomic_load(&slowCount[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while (h < n) {
-                        unsigned batch = (n - h) / (2u * nWaves);
-                        batch = batch < 1u ? 1u : (batch > 64u ? 64u : batch);
-                        const unsigned want = (n - h) < batch ? n : h + batch;
-                        const unsigned old = atomicCAS(&slowCount[3], h, want);
-                        if (old == h) { k = h; k2 = want; break; }
-                        h = old;
-                    }
-                }
-                k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
-                k2 = (unsigned)__builtin_amdgcn_readfirstlane((int)k2);
-                if (k2 == k) break;  // nothing below the count that is not somebody's already
-                for (unsigned i = k; i < k2; i++) {
-                    int got = -1;
-                    if (lane == 0) {
-                        // (bounded: a store in flight arrives within microseconds; the bound only keeps a wavefront from
-                        // spinning for ever should an entry never come -- every wavefront must reach its end)
-                        for (int spin = 0; spin < (1 << 20); spin++) {
-                            got = __hip_atomic_load(&slowList[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (got >= 0) break;
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        if (got >= 0) __hip_atomic_store(&slowList[i], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    got = __builtin_amdgcn_readfirstlane(got);
-                    if (got < 0) continue;
-                    const unsigned slot = (unsigned)got;
-                    const unsigned rsl = index ? (unsigned)index[slot] : slot;
-                    const size_t rs = ANYHIT ? (size_t)slot : (size_t)rsl;
-                    const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
-                    int bTri, bSeq;
-                    float bT, bB, bG;
-                    slow_walk_wave<ANYHIT, COUNT, kBlk>(s, vec3{r0.x, r0.y, r0.z}, vec3{r1.x, r1.y, r1.z}, r0.w, r1.w, wstack,
-                                                        64 * kWideMaxDepth, lane, bTri, bSeq, bT, bB, bG, nv, nt);
-                    if (lane == 0) {
-                        if (ANYHIT) {
-                            if (bTri >= 0) occ[target ? (unsigned)target[slot] : slot] = 1;
-                        } else {
-                            hits[rsl] = make_float4(i2f(bTri), bT, bB, bG);
-                        }
-                    }
-                    wave_lds_sync();
-                }
-            }
-            if (pass == 1) break;
-            int last = 0;
+        const unsigned drainMax = 2u * nWaves;
+        // one handed-back ray, by the whole wavefront
+        auto traceEntry = [&](const unsigned i) {
+            int got = -1;
             if (lane == 0) {
-                if (__hip_atomic_fetch_add(&poolCtl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(kBlk / 64) - 1u)
-                    last = atomicAdd(&slowCount[2], 1u) == gridDim.x - 1u ? 1 : 0;
+                // (bounded: a store in flight arrives within microseconds; the bound only keeps a wavefront from spinning
+                // for ever should an entry never come -- every wavefront must reach its end)
+                for (int spin = 0; spin < (1 << 20); spin++) {
+                    got = __hip_atomic_load(&slowList[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (got >= 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (got >= 0) __hip_atomic_store(&slowList[i], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (!__builtin_amdgcn_readfirstlane(last)) break;
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got < 0) return;
+            const unsigned slot = (unsigned)got;
+            const unsigned rsl = index ? (unsigned)index[slot] : slot;
+            const size_t rs = ANYHIT ? (size_t)slot : (size_t)rsl;
+            const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
+            int bTri, bSeq;
+            float bT, bB, bG;
+            slow_walk_wave<ANYHIT, COUNT, kBlk>(s, vec3{r0.x, r0.y, r0.z}, vec3{r1.x, r1.y, r1.z}, r0.w, r1.w, wstack, 64 * kWideMaxDepth,
+                                                lane, bTri, bSeq, bT, bB, bG, nv, nt);
+            if (lane == 0) {
+                if (ANYHIT) {
+                    if (bTri >= 0) occ[target ? (unsigned)target[slot] : slot] = 1;
+                } else {
+                    hits[rsl] = make_float4(i2f(bTri), bT, bB, bG);
+                }
+            }
+            wave_lds_sync();
+        };
+        // this wavefront's share: entries gw, gw + nWaves, ... below the count, until the count stops growing under it
+        unsigned seen = 0u;
+        for (;;) {
+            unsigned n = 0u;
+            if (lane == 0) n = __hip_atomic_load(slowCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n = (unsigned)__builtin_amdgcn_readfirstlane((int)n);
+            if (n == seen || n > drainMax) break;
+            unsigned i = seen + (gw + nWaves - seen % nWaves) % nWaves;  // the first index >= seen that is gw mod nWaves
+            for (; i < n; i += nWaves) traceEntry(i);
+            seen = n;
+        }
+        int last = 0;
+        if (lane == 0) {
+            // the least `seen`: per block in LDS, then one atomic per BLOCK on the header (4,096 wavefronts that end
+            // together would otherwise queue on one address: 0.19 ms per launch when tried)
+            __hip_atomic_fetch_min(&poolCtl[3], seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__hip_atomic_fetch_add(&poolCtl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(kBlk / 64) - 1u) {
+                const unsigned least = __hip_atomic_load(&poolCtl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&slowCount[3], ~least, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the header keeps the complement
+                __builtin_amdgcn_s_waitcnt(0);
+                last = atomicAdd(&slowCount[2], 1u) == gridDim.x - 1u ? 1 : 0;
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane(last)) {
+            // every other wavefront has finished its share; what arrived after its owner had gone lies at or above the
+            // least `seen`
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            unsigned n = 0u, from = 0u;
+            if (lane == 0) {
+                n = __hip_atomic_load(slowCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                from = ~__hip_atomic_load(&slowCount[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            n = (unsigned)__builtin_amdgcn_readfirstlane((int)n);
+            from = (unsigned)__builtin_amdgcn_readfirstlane((int)from);
+            if (n <= drainMax) {
+                for (unsigned base = from; base < n; base += 64u) {
+                    int e = -1;
+                    if (base + (unsigned)lane < n) e = __hip_atomic_load(&slowList[base + (unsigned)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long m = __ballot(e >= 0);
+                    while (m != 0ull) {
+                        const int j = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        traceEntry(base + (unsigned)j);
+                    }
+                }
+            }
         }
     }
 #endif
