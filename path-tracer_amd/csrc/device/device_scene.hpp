@@ -114,6 +114,9 @@ constexpr int kWideK = PT_WIDE_K;
 // + 16 [d >= 0]): two 16-B loads per axis, no selects.  112 B in LDS, 128-B records in the arena (one cache line).
 constexpr int kWideNodeF4 = 7;
 constexpr int kWideNodeStrideF4 = 8;
+#ifndef PT_TUNE_WIDE_LDS128
+#define PT_TUNE_WIDE_LDS128 1  // 1: the copy of the tree's top in LDS keeps the arena's 128-B records, so a visit forms ONE set of piece addresses for both homes of a node (and no multiply by 112); 0: packed, 112 B per node (753 instead of 659 nodes)
+#endif
 #elif PT_WIDE_HALF
 constexpr int kWideNodeF4 = 4;        // 16-B rows per wide node: x, y, z planes as 8 halves {lo of slots 0..3, hi of slots 0..3}, meta
 constexpr int kWideNodeStrideF4 = 4;  // 64-B records, 64-B aligned: a node never straddles a cache line
@@ -126,6 +129,11 @@ constexpr int kWideNodeStrideF4 = PT_TUNE_WIDE_NODE_STRIDE;  // ... and in the a
 #endif
 #ifndef PT_TUNE_LEAFHEAD_STRIDE
 #define PT_TUNE_LEAFHEAD_STRIDE 3
+#endif
+#if PT_WIDE_K == 8 && PT_TUNE_WIDE_LDS128
+constexpr int kWideNodeLdsF4 = kWideNodeStrideF4;  // float4 per wide node in LDS
+#else
+constexpr int kWideNodeLdsF4 = kWideNodeF4;
 #endif
 constexpr int kLeafHeadStrideF4 = PT_TUNE_LEAFHEAD_STRIDE;   // float4 per leafHead record (4 = half a line each)
 constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's per-lane stack can hold (binary depth 32)
@@ -144,7 +152,7 @@ constexpr int kWideMaxDepth = 16;   // levels of the wide tree k_trace_wide's pe
 #define PT_WIDE_SHARE (PT_WIDE_K == 8)
 #endif
 #ifndef PT_TUNE_WIDE_TOP
-#define PT_TUNE_WIDE_TOP ((163840 / PT_TUNE_WIDE_PER_CU - 640 - (4 * kWideMaxDepth + 13 * PT_WIDE_SHARE) * PT_TUNE_WIDE_BLOCK) / (16 * kWideNodeF4))
+#define PT_TUNE_WIDE_TOP ((163840 / PT_TUNE_WIDE_PER_CU - 640 - (4 * kWideMaxDepth + 13 * PT_WIDE_SHARE) * PT_TUNE_WIDE_BLOCK) / (16 * kWideNodeLdsF4))
 #endif
 constexpr int kWideBlocksPerCU = PT_TUNE_WIDE_PER_CU;
 constexpr int kWideTopNodes = PT_TUNE_WIDE_TOP;

@@ -336,7 +336,7 @@ struct WideLds {
                                   // [2] wavefronts of this block that have left the main loop
 };
 #define PT_WIDE_LDS_DECL(KBLK, KTOP)                                                                       \
-    __shared__ float4 ldsTop[kWideNodeF4 * (KTOP)];                                                        \
+    __shared__ float4 ldsTop[kWideNodeLdsF4 * (KTOP)];                                                     \
     __shared__ unsigned ldsStack[kWideMaxDepth * (KBLK)];                                                  \
     __shared__ unsigned ldsPrefix[2][kShards + 1];                                                         \
     __shared__ unsigned char ldsPair[(PT_WIDE_SHARE && PT_WIDE_K == 8) ? (KBLK) : 1];                      \
@@ -346,8 +346,8 @@ struct WideLds {
     __shared__ unsigned ldsPoolCtl[2][4]
 // the top of the tree into LDS (packed there, kWideNodeStrideF4 apart in the arena)
 __device__ __forceinline__ void wide_load_top(const DevScene& s, float4* top, int nTop, int kBlk) {
-    for (int i = threadIdx.x; i < kWideNodeF4 * nTop; i += kBlk)
-        top[i] = s.wnodes[(i / kWideNodeF4) * kWideNodeStrideF4 + i % kWideNodeF4];
+    for (int i = threadIdx.x; i < kWideNodeLdsF4 * nTop; i += kBlk)
+        top[i] = s.wnodes[(i / kWideNodeLdsF4) * kWideNodeStrideF4 + i % kWideNodeLdsF4];
 }
 // static first chunks: a wavefront's share of three quarters of the queue, 64 .. 1024 rays (see "The queue cursor" in the body)
 __device__ __forceinline__ unsigned wide_static_chunk(unsigned total, unsigned nWaves) {
@@ -792,6 +792,22 @@ __device__ __forceinline__ void wide_body(
                 half8v nx8, fx8, ny8, fy8, nz8, fz8;
                 float4v meta;
 #define PT_PIECE(AS, T, BASE, OFS) (*(const __attribute__((address_space(AS))) T*)((const __attribute__((address_space(AS))) char*)(BASE) + (OFS)))
+#if PT_TUNE_WIDE_LDS128
+                // both homes keep 128-B records: one set of piece addresses
+                const unsigned a = (unsigned)w << 7;
+                const unsigned aNx = a + oNx, aFx = a + oFx, aNy = a + oNy, aFy = a + oFy, aNz = a + oNz, aFz = a + oFz;
+                if (w < nTop) {  // top of the tree: from LDS
+                    nx8 = PT_PIECE(3, half8v, topLds, aNx); fx8 = PT_PIECE(3, half8v, topLds, aFx);
+                    ny8 = PT_PIECE(3, half8v, topLds, aNy); fy8 = PT_PIECE(3, half8v, topLds, aFy);
+                    nz8 = PT_PIECE(3, half8v, topLds, aNz); fz8 = PT_PIECE(3, half8v, topLds, aFz);
+                    meta = PT_PIECE(3, float4v, topLds, a + 96u);
+                } else {
+                    nx8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)aNx); fx8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)aFx);
+                    ny8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)aNy); fy8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)aFy);
+                    nz8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)aNz); fz8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)aFz);
+                    meta = PT_PIECE(1, float4v, nodesGlobal, (size_t)(a + 96u));
+                }
+#else
                 if (w < nTop) {  // top of the tree: from LDS, 112-B records
                     const unsigned a = __umul24((unsigned)w, 112u);
                     nx8 = PT_PIECE(3, half8v, topLds, a + oNx); fx8 = PT_PIECE(3, half8v, topLds, a + oFx);
@@ -805,6 +821,7 @@ __device__ __forceinline__ void wide_body(
                     nz8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)(a + oNz)); fz8 = PT_PIECE(1, half8v, nodesGlobal, (size_t)(a + oFz));
                     meta = PT_PIECE(1, float4v, nodesGlobal, (size_t)(a + 96u));
                 }
+#endif
 #undef PT_PIECE
                 const int counts = f2i(meta.z);
                 const int nInt = counts & 255;  // interior slots come first, then the leaf slots; the EMPTY slots behind them hold
