@@ -1030,7 +1030,6 @@ int ensure_slow(mipt_ctx* c, DevBuf& buf, int& parity, size_t capacity, hipStrea
 // long list, a tree too deep for its exact walk -- is looked after by list-mode k_trace, which returns at once when nothing
 // is left.  (A launch that emptied lists of any length through a claim cursor, and no follow-up, was tried: 1,500 entries
 // took 23 ms.)  The short-list kernel k_trace_slow runs only when the in-kernel drain is off.
-inline bool drained_in_kernel(const mipt_ctx*) { return false; }
 void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView q, unsigned* cursor, float4* hits) {
     if (!cursor) {
         cursor = (unsigned*)(c->dTotals + 6);
@@ -1043,10 +1042,8 @@ void trace_closest(mipt_ctx* c, const float4* rays, const int* index, QueueView 
         launch_trace_bittrail_closest(c->stream, c->ds, rays, index, q, hits, cnt);
     } else if (SlowView v{}; c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slow, c->slowParity, q.space, c->stream, v) == MIPT_OK) {
         launch_trace_wide_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt, v.head, v.list, v.next);
-        if (!drained_in_kernel(c)) {  // else k_trace_wide's own wavefronts have emptied the list, whatever its length
-            if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, v.list, v.head);  // short list: a wavefront per ray
-            launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, v.head + 1, hits, cnt, v.list, v.head);  // long list, deep tree: a lane per ray
-        }
+        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, index, hits, cnt, v.list, v.head);  // short list: a wavefront per ray
+        launch_trace_closest(c->stream, c->ds, rays, index, QueueView{nullptr, 0u, q.space}, v.head + 1, hits, cnt, v.list, v.head);  // long list, deep tree: a lane per ray
     } else {
         launch_trace_closest(c->stream, c->ds, rays, index, q, cursor, hits, cnt);
     }
@@ -1067,10 +1064,8 @@ void trace_occluded(mipt_ctx* c, const float4* rays, const int* target, QueueVie
         launch_trace_bittrail_occluded(st, c->ds, rays, target, q, occ, cnt);
     } else if (SlowView v{}; c->ds.nWide > 0 && c->useWide && ensure_slow(c, c->slowOcc, c->slowOccParity, q.space, st, v) == MIPT_OK) {
         launch_trace_wide_occluded(st, c->ds, rays, target, q, cursor, occ, cnt, v.head, v.list, v.next);
-        if (!drained_in_kernel(c)) {
-            if (!c->ds.drain) launch_trace_slow_occluded(st, c->ds, rays, target, occ, cnt, v.list, v.head);
-            launch_trace_occluded(st, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, v.head + 1, occ, cnt, v.list, v.head);
-        }
+        if (!c->ds.drain) launch_trace_slow_occluded(st, c->ds, rays, target, occ, cnt, v.list, v.head);
+        launch_trace_occluded(st, c->ds, rays, target, QueueView{nullptr, 0u, q.space}, v.head + 1, occ, cnt, v.list, v.head);
     } else {
         launch_trace_occluded(st, c->ds, rays, target, q, cursor, occ, cnt);
     }
@@ -1091,12 +1086,10 @@ bool trace_both(mipt_ctx* c, const float4* raysC, const int* indexC, QueueView q
     unsigned long long* cntO = c->counting ? c->dTotals + 4 : nullptr;
     launch_trace_wide_both(c->stream, c->ds, raysC, indexC, qC, cursorC, hits, cntC, vc.head, vc.list, raysO, targetO, qO, cursorO, occ,
                            cntO, vo.head, vo.list, c->shadowFirst ? 1 : 0, vc.next, vo.next);
-    if (!drained_in_kernel(c)) {
-        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, raysC, indexC, hits, cntC, vc.list, vc.head);
-        launch_trace_closest(c->stream, c->ds, raysC, indexC, QueueView{nullptr, 0u, qC.space}, vc.head + 1, hits, cntC, vc.list, vc.head);
-        if (!c->ds.drain) launch_trace_slow_occluded(c->stream, c->ds, raysO, targetO, occ, cntO, vo.list, vo.head);
-        launch_trace_occluded(c->stream, c->ds, raysO, targetO, QueueView{nullptr, 0u, qO.space}, vo.head + 1, occ, cntO, vo.list, vo.head);
-    }
+    if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, raysC, indexC, hits, cntC, vc.list, vc.head);
+    launch_trace_closest(c->stream, c->ds, raysC, indexC, QueueView{nullptr, 0u, qC.space}, vc.head + 1, hits, cntC, vc.list, vc.head);
+    if (!c->ds.drain) launch_trace_slow_occluded(c->stream, c->ds, raysO, targetO, occ, cntO, vo.list, vo.head);
+    launch_trace_occluded(c->stream, c->ds, raysO, targetO, QueueView{nullptr, 0u, qO.space}, vo.head + 1, occ, cntO, vo.list, vo.head);
     return true;
 #else
     return false;
@@ -1918,10 +1911,8 @@ int mipt_trace_device_noalloc(mipt_ctx* c, const void* rays_dev, size_t n, void*
         launch_trace_bittrail_closest(c->stream, c->ds, rays, nullptr, q, hits, cnt);
     } else if (c->ds.nWide > 0 && c->useWide) {
         launch_trace_wide_closest(c->stream, c->ds, rays, nullptr, q, cursor, hits, cnt, head, list);
-        if (!drained_in_kernel(c)) {
-            if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, nullptr, hits, cnt, list, head);
-            launch_trace_closest(c->stream, c->ds, rays, nullptr, QueueView{nullptr, 0u, q.space}, head + 1, hits, cnt, list, head);
-        }
+        if (!c->ds.drain) launch_trace_slow_closest(c->stream, c->ds, rays, nullptr, hits, cnt, list, head);
+        launch_trace_closest(c->stream, c->ds, rays, nullptr, QueueView{nullptr, 0u, q.space}, head + 1, hits, cnt, list, head);
     } else {
         launch_trace_closest(c->stream, c->ds, rays, nullptr, q, cursor, hits, cnt);
     }

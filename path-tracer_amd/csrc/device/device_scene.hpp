@@ -100,7 +100,7 @@ constexpr int kTriAttrF4 = 8;       // float4 per triAttr record
 #define PT_WIDE_HALF 1  // wide nodes with fp16 planes rounded outwards (64 B, four 16-B rows); 0: fp32 planes (112 B, seven rows)
 #endif
 #ifndef PT_WIDE_DRAIN
-#define PT_WIDE_DRAIN 1  // k_trace_wide's wavefronts trace the rays the launch has handed back themselves ("Draining the hand-back list" in kernels_trace_wide.hip); the host then launches no follow-up kernel (api_device.hip)
+#define PT_WIDE_DRAIN 1  // k_trace_wide's wavefronts trace the rays the launch has handed back themselves ("Draining the hand-back list" in kernels_trace_wide.hip); short lists only: list-mode k_trace follows every launch and looks after what is left (api_device.hip)
 #endif
 #ifndef PT_WIDE_K
 #define PT_WIDE_K 8  // slots per wide node: 8 (default since r2: 12 instead of 19 dependent visits per closest-hit ray) or 4; 8 needs PT_WIDE_HALF
