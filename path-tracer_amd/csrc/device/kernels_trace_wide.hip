@@ -332,8 +332,7 @@ struct WideLds {
     unsigned long long* key;      // per owner lane: min over its helpers of t << 32 | index
     unsigned* out;                // per owner lane: helpers still out | failed << 31
     unsigned long long* pool;     // the block's pool of rays: next dense index << 32 | end of the chunk
-    unsigned* poolCtl;            // [0] lock of the one wavefront that refills the pool, [1] the launch's queue is empty,
-                                  // [2] wavefronts of this block that have left the main loop
+    unsigned* poolCtl;            // [0] lock of the one wavefront that refills the pool, [1] the launch's queue is empty
 };
 #define PT_WIDE_LDS_DECL(KBLK, KTOP)                                                                       \
     __shared__ float4 ldsTop[kWideNodeLdsF4 * (KTOP)];                                                     \
@@ -379,8 +378,6 @@ __device__ __forceinline__ void wide_prefix(const QueueView& q, unsigned* prefix
         *pool = ((unsigned long long)base << 32) | (unsigned long long)(base + len);
         poolCtl[0] = 0u;
         poolCtl[1] = (unsigned long long)gridDim.x * C0 >= (unsigned long long)total ? 1u : 0u;  // nothing behind the static chunks
-        poolCtl[2] = 0u;
-        poolCtl[3] = 0xffffffffu;  // the least list count a draining wavefront of this block has seen
     }
 }
 
@@ -1098,11 +1095,13 @@ __device__ __forceinline__ void wide_body(
     // the earlier ones took.  A compare-and-swap cursor: all wavefronts arrive at once, one wins per round, and a list
     // of 1,500 entries took 23 ms.)  The owner puts -1 back, the list's resting state, BEFORE it traces the ray.  An entry
     // may be a moment behind its count -- its producer, a running wavefront that waits for nobody, is between its
-    // atomicAdd and its store -- so the owner reads it until it is there (bounded).  A wavefront then records how much of
-    // the list it has seen (header word 3 keeps the complement of the minimum) and counts itself off; entries that arrive
-    // after their owner has gone are orphans, all of them at or above that minimum, and the last wavefront of the last
-    // block -- which sees the final count, and runs when every owner has finished -- traces those.  Nobody waits for
-    // anything but a store in flight, so blocks that are not resident yet cannot be waited for.
+    // atomicAdd and its store -- so the owner reads it until it is there (bounded).  A wavefront looks at the count, traces
+    // its entries below it, looks again, and leaves when the count has stopped growing under it.  Nobody waits for
+    // anything but a store in flight, so blocks that are not resident yet cannot be waited for.  An entry that arrives
+    // after its owner has gone (a verdict that failed late in the launch; the rays of a launch so small that most of its
+    // wavefronts leave before the first ray is handed back) stays in the list for the launch that follows, list-mode
+    // k_trace.  (A version in which the launch's last wavefront traced those itself, one after the other, made a launch
+    // of 16 axis-parallel rays take 124 us.)
     // Only SHORT lists are emptied here: up to two entries per wavefront of the launch (the usual few dozen rays of a frame;
     // all of a launch's rays when they are few).  A longer list -- a batch of axis-parallel rays, say, none of which
     // qualifies -- is work for every LANE, not for a wavefront per ray, and wavefronts that leave early would orphan most
@@ -1110,11 +1109,10 @@ __device__ __forceinline__ void wide_body(
     // skips what has been taken; the same launch looks after trees too deep for this walk's stack (!slowOk).
     // (Visibility without fences: an agent-scope fence writes the whole L2 of the wavefront's XCD back -- 4,096 of them cost
     // 160 us per launch when tried.  The list is therefore written, read and reset with agent-scope ATOMICS only, which
-    // act at the memory side and need no cache maintenance, and a wavefront waits for its own outstanding memory
-    // operations (s_waitcnt) before it counts itself off, so that its entries are there when the count says so.)
+    // act at the memory side and need no cache maintenance.)
     if (s.drain && s.slowOk) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);  // this wavefront's own entries are out before it is counted off
+        __builtin_amdgcn_s_waitcnt(0);  // this wavefront's own entries are out before it looks at the list
         int* const wstack = (int*)stackLds + waveBase;
         const unsigned drainMax = 2u * nWaves;
         // one handed-back ray, by the whole wavefront
@@ -1159,42 +1157,6 @@ __device__ __forceinline__ void wide_body(
             unsigned i = seen + (gw + nWaves - seen % nWaves) % nWaves;  // the first index >= seen that is gw mod nWaves
             for (; i < n; i += nWaves) traceEntry(i);
             seen = n;
-        }
-        int last = 0;
-        if (lane == 0) {
-            // the least `seen`: per block in LDS, then one atomic per BLOCK on the header (4,096 wavefronts that end
-            // together would otherwise queue on one address: 0.19 ms per launch when tried)
-            __hip_atomic_fetch_min(&poolCtl[3], seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__hip_atomic_fetch_add(&poolCtl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(kBlk / 64) - 1u) {
-                const unsigned least = __hip_atomic_load(&poolCtl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_max(&slowCount[3], ~least, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the header keeps the complement
-                __builtin_amdgcn_s_waitcnt(0);
-                last = atomicAdd(&slowCount[2], 1u) == gridDim.x - 1u ? 1 : 0;
-            }
-        }
-        if (__builtin_amdgcn_readfirstlane(last)) {
-            // every other wavefront has finished its share; what arrived after its owner had gone lies at or above the
-            // least `seen`
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            unsigned n = 0u, from = 0u;
-            if (lane == 0) {
-                n = __hip_atomic_load(slowCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                from = ~__hip_atomic_load(&slowCount[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            n = (unsigned)__builtin_amdgcn_readfirstlane((int)n);
-            from = (unsigned)__builtin_amdgcn_readfirstlane((int)from);
-            if (n <= drainMax) {
-                for (unsigned base = from; base < n; base += 64u) {
-                    int e = -1;
-                    if (base + (unsigned)lane < n) e = __hip_atomic_load(&slowList[base + (unsigned)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    unsigned long long m = __ballot(e >= 0);
-                    while (m != 0ull) {
-                        const int j = __builtin_ctzll(m);
-                        m &= m - 1ull;
-                        traceEntry(base + (unsigned)j);
-                    }
-                }
-            }
         }
     }
 #endif
