@@ -40,7 +40,7 @@ namespace ptd {
 #endif
 #ifndef PT_TUNE_WIDE_BURST
 #if PT_WIDE_K == 8
-#define PT_TUNE_WIDE_BURST 8          // eight-slot nodes: 8: 4.22 ms per closest-hit bench launch, 12: 4.26, 16: 4.40
+#define PT_TUNE_WIDE_BURST 10         // eight-slot nodes: 8: 4.22 ms per closest-hit bench launch, 12: 4.26, 16: 4.40; at the end of r3 (108 VGPRs, cheaper visits): 6: 3.89, 8: 3.83, 10: 3.79, 12: 3.80, 14: 3.88
 #else
 #define PT_TUNE_WIDE_BURST 16         // visits between two votes, closest hit (r2, fp16 nodes: 6: 5.42 ms per bench launch, 8: 5.25, 12: 5.07, 16: 5.09, 24: 5.35; with the rebuilt hierarchy: 8: 4.72, 12: 4.56, 16: 4.53, 20: 4.64)
 #endif
@@ -78,7 +78,7 @@ namespace ptd {
 #endif
 #ifndef PT_TUNE_WIDE_BURST_ANYHIT
 #if PT_WIDE_K == 8
-#define PT_TUNE_WIDE_BURST_ANYHIT 6   // eight-slot nodes: 2: 1.45 ms per any-hit bench launch, 3: 1.37, 4: 1.39, 6: 1.31, 8: 1.35
+#define PT_TUNE_WIDE_BURST_ANYHIT 5   // eight-slot nodes: 2: 1.45 ms per any-hit bench launch, 3: 1.37, 4: 1.39, 6: 1.31, 8: 1.35; at the end of r3 (88 VGPRs): 3: 1.08, 4: 1.14, 5: 0.96, 6: 1.05, 8: 1.14 (not monotonic, and the same on every run: profiles/r03/tune_sweep_r3_end.txt)
 #else
 #define PT_TUNE_WIDE_BURST_ANYHIT 4   // ... any hit: rays end early, shorter bursts waste fewer visits (3: 1.70 ms, 4: 1.62, 6: 1.67)
 #endif
@@ -210,6 +210,11 @@ __device__ __forceinline__ int wide_hit_mask_fma(const float4v nearx, const floa
 #ifndef PT_TUNE_WIDE_CARRY_ID
 #define PT_TUNE_WIDE_CARRY_ID 1  // 1: the winning triangle's id is carried in a register (there is room since the `precise` form left); 0: looked up in leafTris when the ray finishes, a dependent load every wavefront waited for after nearly every burst
 #endif
+#ifndef PT_TUNE_WIDE_BURST_UNROLL
+#define PT_TUNE_WIDE_BURST_UNROLL 1  // visits of a burst per turn of its loop (0: unrolled in full)
+#endif
+#define PT_PRAGMA_(X) _Pragma(#X)
+#define PT_PRAGMA(X) PT_PRAGMA_(X)
 #ifndef PT_TUNE_WIDE_SIGNMASK
 #define PT_TUNE_WIDE_SIGNMASK 1  // the slot test's hit mask from the sign bits of v - u (wide_hit_mask_fma_h)
 #endif
@@ -777,7 +782,11 @@ __device__ __forceinline__ void wide_body(
         }
         if (nEmpty == 64) continue;  // nothing else to do yet (the refill may have found rays: look again)
         // ---- visits: lanes with a node to visit and room for one more leaf group ----
+#if PT_TUNE_WIDE_BURST_UNROLL
+        PT_PRAGMA(unroll PT_TUNE_WIDE_BURST_UNROLL)
+#else
 #pragma unroll
+#endif
         for (int b = 0; b < (ANYHIT ? PT_TUNE_WIDE_BURST_ANYHIT : PT_TUNE_WIDE_BURST); b++) {
             if (PT_TUNE_WIDE_TAIL_BURST > 0 && SHARE && exhausted && b >= PT_TUNE_WIDE_TAIL_BURST) break;  // the tail: shorter turns, work spreads sooner
 #if PT_DIAG_UTIL == 1

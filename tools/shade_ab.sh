@@ -12,6 +12,6 @@ for name in "$@"; do
   python3 - "$name" $root/gpurun_out/shade_ab/$name.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2])); pk = d["roofline"]["per_kernel"]
-print(f'{sys.argv[1]:12s} {d["value"]:8.1f} Mrays/s  step {d["ms_per_step"]:7.3f} ms  serialised {d["config"]["ms_per_step_serialised_with_events"]:7.3f}  shade {pk["k_shade_path"]["avg_launch_ms"]:6.3f} ms  closest {pk["k_trace_closest"]["avg_launch_ms"]:6.3f}', flush=True)
+print(f'{sys.argv[1]:12s} {d["value"]:8.1f} Mrays/s  step {d["ms_per_step"]:7.3f} ms  serialised {d["config"]["ms_per_step_serialised_with_events"]:7.3f}  shade {pk["k_shade_path"]["avg_launch_ms"]:6.3f} ms  closest {pk["k_trace_closest"]["avg_launch_ms"]:6.3f}  any-hit {pk["k_trace_occluded"]["avg_launch_ms"]:6.3f}', flush=True)
 PY
 done
