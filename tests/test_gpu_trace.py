@@ -226,6 +226,29 @@ def test_axis_parallel_rays_from_vertices(B, ob, sf, name):
         assert np.array_equal(ctx.occluded(o, d, tmin, tmax), orc.occluded(o, d, tmin, tmax))
 
 
+@pytest.mark.parametrize("n_axis,n_other", [(1, 0), (16, 0), (70, 0), (16, 5000), (300, 200000), (20000, 100000)])
+def test_handed_back_rays_of_every_list_length(B, ob, sf, n_axis, n_other):
+    """the rays k_trace_wide hands back are traced by their owner wavefronts inside the launch when the list is short,
+    by list-mode k_trace after it when it is long or when an entry arrives after its owner has gone (a launch of a
+    few rays: most wavefronts leave before the first one is handed back): every split of the work gives the oracle's
+    bits, for lists of 1 to 20,000 entries alone and among ordinary rays"""
+    scene, ctx, orc = setup_scene(B, sf, "sponza-standin-trace")
+    pos = np.asarray(sf.sponza_standin(1)[0], np.float32).reshape(-1, 3)
+    lo, hi = pos.min(0), pos.max(0)
+    rng = np.random.default_rng(n_axis * 7 + n_other)
+    n = n_axis + n_other
+    o = (lo + (hi - lo) * rng.uniform(0.05, 0.95, (n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    which = rng.permutation(n)[:n_axis]
+    d[which, rng.integers(0, 3, n_axis)] = 0.0  # a zero component: never qualifies
+    for _ in range(2):  # twice: the list headers are used in turn
+        a = ctx.trace(o, d)
+        b = orc.intersect(o, d)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[2]), bits(b[2]))
+        assert np.array_equal(ctx.occluded(o, d, 1e-4, 2.5), orc.occluded(o, d, 1e-4, 2.5))
+
+
 @pytest.mark.parametrize("name", ["cornellbox", "teapot-glass", "testObj"])
 def test_literal_walk_and_wide_traversal_agree(B, ob, sf, name, monkeypatch):
     """MIPT_TRAVERSAL=walk forces the literal threaded walk (k_trace) for a context; both it and the default
