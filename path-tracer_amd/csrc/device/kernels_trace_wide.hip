@@ -215,6 +215,9 @@ __device__ __forceinline__ int wide_hit_mask_fma(const float4v nearx, const floa
 #endif
 #define PT_PRAGMA_(X) _Pragma(#X)
 #define PT_PRAGMA(X) PT_PRAGMA_(X)
+#ifndef PT_TUNE_WIDE_GROUPS_ANYHIT
+#define PT_TUNE_WIDE_GROUPS_ANYHIT 1
+#endif
 #ifndef PT_TUNE_WIDE_SIGNMASK
 #define PT_TUNE_WIDE_SIGNMASK 1  // the slot test's hit mask from the sign bits of v - u (wide_hit_mask_fma_h)
 #endif
@@ -412,6 +415,10 @@ __device__ __forceinline__ void wide_body(
     // Lanes of one wavefront run in lockstep and its LDS operations complete in program order, so no more than the
     // compiler's ordering is needed.  The COUNT instantiations do not share: their visit counts stay a function of the
     // ray alone.
+    // leaf groups a lane may hold before it stops visiting (one group = the hit leaf slots of one wide node).  An any-hit ray
+    // holds ONE: its leaves are opened before it walks on, because the first accepted triangle ends it (r3: 0.968 -> 0.941 ms
+    // per any-hit bench launch; 2 and 3: as 4)
+    constexpr int kG = ANYHIT ? PT_TUNE_WIDE_GROUPS_ANYHIT : kWideGroups;
     constexpr bool SHARE = PT_WIDE_SHARE && (PT_WIDE_K == 8) && !COUNT;
     unsigned char* const pairLds = lds.pair;
     unsigned long long* const shareKey = lds.key;
@@ -434,7 +441,7 @@ __device__ __forceinline__ void wide_body(
     int role = -1; // -1: the lane owns its ray alone | -2: owns it and has given parts away | >= 0: helps that lane of this wavefront
     // leaf groups still to be opened (LIFO, g[0] on top; order is free) and the open leaf's triangle cursor
     int groups = 0;
-    unsigned g[kWideGroups] = {};  // compile-time indices only: registers
+    unsigned g[kG] = {};  // compile-time indices only: registers
     int cur = -1, curLeaf = 0;
     unsigned raySlot = 0, queueSlot = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, yx = 0, yy = 0, yz = 1;  // ray; y = RN(1/d)
@@ -658,7 +665,7 @@ __device__ __forceinline__ void wide_body(
                         if (sp > bot) { gEntry = stack[bot]; bot += kBlk; }
                         else { gEntry = tos; tos = 0u; }
                     } else {
-                        gEntry = groups >= 4 ? g[kWideGroups - 1] : (groups == 3 ? g[2] : (groups == 2 ? g[1] : g[0]));
+                        gEntry = groups >= 4 ? g[kG - 1] : (groups == 3 ? g[kG > 2 ? 2 : kG - 1] : (groups == 2 ? g[kG > 1 ? 1 : 0] : g[0]));
                         --groups;
                     }
                     pairLds[waveBase + (unsigned)rankG] = (unsigned char)lane;
@@ -790,9 +797,9 @@ __device__ __forceinline__ void wide_body(
         for (int b = 0; b < (ANYHIT ? PT_TUNE_WIDE_BURST_ANYHIT : PT_TUNE_WIDE_BURST); b++) {
             if (PT_TUNE_WIDE_TAIL_BURST > 0 && SHARE && exhausted && b >= PT_TUNE_WIDE_TAIL_BURST) break;  // the tail: shorter turns, work spreads sooner
 #if PT_DIAG_UTIL == 1
-            if (COUNT) { const unsigned long long ma = __ballot(w >= 0 && groups < kWideGroups); if (ma) { nv += (w >= 0 && groups < kWideGroups) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; } }
+            if (COUNT) { const unsigned long long ma = __ballot(w >= 0 && groups < kG); if (ma) { nv += (w >= 0 && groups < kG) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; } }
 #endif
-            if (w >= 0 && groups < kWideGroups) {
+            if (w >= 0 && groups < kG) {
 #if PT_WIDE_K == 8
                 // seven 16-B pieces per node from either home: near and far half-rows of x, y, z (picked by address), meta
                 half8v nx8, fx8, ny8, fy8, nz8, fz8;
@@ -849,7 +856,7 @@ __device__ __forceinline__ void wide_body(
                 const int lh = hm >> nInt, ih = hm & ((1 << nInt) - 1);  // lh: bit k = leaf slot k of this node
                 if (lh != 0) {  // park the candidate leaves of this node as one group
 #pragma unroll
-                    for (int k = kWideGroups - 1; k > 0; k--) g[k] = g[k - 1];
+                    for (int k = kG - 1; k > 0; k--) g[k] = g[k - 1];
                     g[0] = ((unsigned)f2i(meta.y) << 8) | (unsigned)lh;
                     ++groups;
                 }
@@ -934,7 +941,7 @@ __device__ __forceinline__ void wide_body(
                 const int lh = hm & lmask, ih = hm & imask;
                 if (lh != 0) {  // park the candidate leaves of this node as one group
 #pragma unroll
-                    for (int k = kWideGroups - 1; k > 0; k--) g[k] = g[k - 1];
+                    for (int k = kG - 1; k > 0; k--) g[k] = g[k - 1];
                     g[0] = pack_group(f2i(meta.y), lmask, lh);
                     ++groups;
                 }
@@ -955,7 +962,7 @@ __device__ __forceinline__ void wide_body(
 #endif  // PT_WIDE_K
         if (PT_WALK_OVER() && (!SHARE || ANYHIT || role == -1)) PT_FINISH();  // walked everything, nothing parked, nothing unverified (lanes that share a ray: at the end of the iteration)
         // ---- leaves: open parked leaves with the exact box test, test their triangles ----
-        const unsigned long long mCanVisit = __ballot(w >= 0 && groups < kWideGroups);
+        const unsigned long long mCanVisit = __ballot(w >= 0 && groups < kG);
         unsigned long long mPend = __ballot(cur >= 0 || groups > 0);
         const unsigned long long mStuck = mPend & ~mCanVisit;
 #if PT_TUNE_WIDE_GREEDY
@@ -988,7 +995,7 @@ __device__ __forceinline__ void wide_body(
                         triOfs = headOfs + (unsigned)curLeaf * (16u * kLeafHeadStrideF4);
                         if ((g[0] & kPendMask) == 0u) {
 #pragma unroll
-                            for (int k = 0; k + 1 < kWideGroups; k++) g[k] = g[k + 1];
+                            for (int k = 0; k + 1 < kG; k++) g[k] = g[k + 1];
                             --groups;
                         }
                     } else {
@@ -1018,10 +1025,10 @@ __device__ __forceinline__ void wide_body(
                 }
                 mPend = __ballot((cur >= 0 || groups > 0) && !(ANYHIT && uLeaf >= 0));
 #if PT_TUNE_WIDE_GREEDY
-            } while (mPend != 0ull && __popcll(mPend) >= __popcll(__ballot(w >= 0 && groups < kWideGroups)));
+            } while (mPend != 0ull && __popcll(mPend) >= __popcll(__ballot(w >= 0 && groups < kG)));
 #else
             } while (__popcll(mPend) >= (ANYHIT ? PT_TUNE_WIDE_KEEP_ANYHIT : PT_TUNE_WIDE_KEEP) ||
-                     (tailGreedy && mPend != 0ull && __popcll(mPend) >= __popcll(__ballot(w >= 0 && groups < kWideGroups))));
+                     (tailGreedy && mPend != 0ull && __popcll(mPend) >= __popcll(__ballot(w >= 0 && groups < kG))));
 #endif
             // ---- the verdicts: exact box predicate of every lane that holds an unverified best ----
             if (uLeaf >= 0) {
