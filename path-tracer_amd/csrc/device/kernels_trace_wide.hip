@@ -216,7 +216,7 @@ __device__ __forceinline__ int wide_hit_mask_fma(const float4v nearx, const floa
 #define PT_PRAGMA_(X) _Pragma(#X)
 #define PT_PRAGMA(X) PT_PRAGMA_(X)
 #ifndef PT_TUNE_WIDE_GROUPS_ANYHIT
-#define PT_TUNE_WIDE_GROUPS_ANYHIT 1
+#define PT_TUNE_WIDE_GROUPS_ANYHIT PT_TUNE_WIDE_GROUPS  // 1: an any-hit ray's leaves are opened before it walks on -- the bench scene, where most shadow rays end at a triangle, gains (41.9 instead of 47.3 slot tests per shadow ray, any-hit launch 0.97 -> 0.92 ms, step -0.6 %), scenes whose shadow rays mostly reach the light lose (bunny +1.8 %, direct-lit bunny +2.7 %, testObj +0.9 %): not the default (profiles/r03 r3v10 against r3v9)
 #endif
 #ifndef PT_TUNE_WIDE_SIGNMASK
 #define PT_TUNE_WIDE_SIGNMASK 1  // the slot test's hit mask from the sign bits of v - u (wide_hit_mask_fma_h)
@@ -415,9 +415,8 @@ __device__ __forceinline__ void wide_body(
     // Lanes of one wavefront run in lockstep and its LDS operations complete in program order, so no more than the
     // compiler's ordering is needed.  The COUNT instantiations do not share: their visit counts stay a function of the
     // ray alone.
-    // leaf groups a lane may hold before it stops visiting (one group = the hit leaf slots of one wide node).  An any-hit ray
-    // holds ONE: its leaves are opened before it walks on, because the first accepted triangle ends it (r3: 0.968 -> 0.941 ms
-    // per any-hit bench launch; 2 and 3: as 4)
+    // leaf groups a lane may hold before it stops visiting (one group = the hit leaf slots of one wide node); see
+    // PT_TUNE_WIDE_GROUPS_ANYHIT for what one group per any-hit ray does
     constexpr int kG = ANYHIT ? PT_TUNE_WIDE_GROUPS_ANYHIT : kWideGroups;
     constexpr bool SHARE = PT_WIDE_SHARE && (PT_WIDE_K == 8) && !COUNT;
     unsigned char* const pairLds = lds.pair;
