@@ -85,8 +85,10 @@ __global__ __launch_bounds__(kBlock) void k_generate(CameraDev cam, FrameParams 
                 pb.rays[2 * (size_t)p] = pack(o, 0.0f);
                 pb.rays[2 * (size_t)p + 1] = pack(d, kFltMax);
             }
-            pb.pixel[p] = pix;
-            pb.res[p] = make_float4(0.0f, 0.0f, 0.0f, i2f(RES_NONE));
+            if (p < fp.nTilePaths) pb.pixel[p] = pix;  // one entry per pixel slot: the samples in flight share it
+            // (res[p] needs no initial value: every path that starts writes it exactly once -- a miss, a capped or
+            // light-hitting vertex, or the pass over the paths that ended at a Lambertian vertex -- before
+            // k_resolve_samples reads it, and slots without a pixel are skipped there)
         }
         const unsigned slot = wave_append(pb.counters + counter_index(0, 0, 0), pb.regionSize, (p >> 6) % (unsigned)kShards, valid);
         if (valid) pb.qExt[0][slot] = (int)p;
@@ -254,8 +256,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams f
                             pb.shTarget[sl] = (int)((size_t)p * nl + k);
                         }
                     }
-                    const int pix = pb.pixel[p];
-                    const unsigned sample = fp.sample + p / fp.nTilePaths;
+                    const unsigned inFlight = p / fp.nTilePaths;  // which of the samples in flight this path is
+                    const int pix = pb.pixel[p - inFlight * fp.nTilePaths];
+                    const unsigned sample = fp.sample + inFlight;
                     bool done = capped;
                     if (!done && it > 5) {  // C:2311-2314, no weight compensation
                         if (counter_rand(fp.seedHash, (unsigned)pix, sample, dim++) < .25f) done = true;

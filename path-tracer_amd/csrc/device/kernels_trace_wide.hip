@@ -18,14 +18,15 @@
 // isHit (cs488.h:1684-1705) returns "some accepted triangle exists", which is order-free by itself.
 //
 // This kernel does that for the rays that qualify (fast_div_ok, in a scene whose planes are tame and whose tree
-// build_wide() accepted): a 4-wide tree (a node's slots = a binary node's children opened largest box first until
-// four are taken), all four boxes of a node tested in straight-line code with a cheap conservative test (plane
+// build_wide() accepted): a wide tree (eight slots per node since round 2, PT_WIDE_K; four before: a node's slots = a
+// binary node's children opened largest box first), all boxes of a node tested in straight-line code with a cheap conservative test (plane
 // offset times a reciprocal that carries the slack, instead of the exact division), a per-lane stack of one packed
 // entry per visited node with hit children, leaves parked and tested later: triangle first, the exact box
 // predicate only for a triangle that would change the result.  One visit replaces about four steps of the threaded
 // walk (the walk spends as many issue slots on its exec-mask juggling per box as on arithmetic: DESIGN.md).  Rays
-// that do not qualify are appended to a list; NaN rays are answered as misses at once; after the launch the list
-// is traced by k_trace_slow (a wavefront per ray) or, when it is long, by the literal k_trace (kernels_trace.hip).
+// that do not qualify are appended to a list; NaN rays are answered as misses at once; a short list is traced by the
+// wavefronts of this launch as they finish (a wavefront per ray: "Draining the hand-back list" below), whatever is
+// left by the literal k_trace after it, a lane per ray (kernels_trace.hip).
 #include "kernels.hpp"
 #include "shading.hpp"
 #include "slow_walk.hpp"
@@ -100,6 +101,8 @@ namespace ptd {
 #if PT_WIDE_K == 8
 // ... with eight-slot nodes (112 B, 121 VGPRs in the closest-hit and ~100 in the any-hit instantiation) five wavefronts
 // spill 23 registers: both instantiations run one 1024-thread block per CU (any-hit 1.38 ms against 1.82 at five).
+// (End of round 3: 103 / 92 VGPRs; two 640-thread blocks per CU at five wavefronts still spill 9 to 17 and halve the
+// tree top in LDS: 5.3 ms per closest-hit bench launch against 3.8.)
 #ifndef PT_TUNE_WIDE_BLOCK_ANYHIT
 #define PT_TUNE_WIDE_BLOCK_ANYHIT 1024
 #endif
