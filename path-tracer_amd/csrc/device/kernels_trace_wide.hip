@@ -221,6 +221,30 @@ __device__ __forceinline__ int wide_hit_mask_fma(const float4v nearx, const floa
 #ifndef PT_TUNE_WIDE_GROUPS_ANYHIT
 #define PT_TUNE_WIDE_GROUPS_ANYHIT PT_TUNE_WIDE_GROUPS  // 1: an any-hit ray's leaves are opened before it walks on -- the bench scene, where most shadow rays end at a triangle, gains (41.9 instead of 47.3 slot tests per shadow ray, any-hit launch 0.97 -> 0.92 ms, step -0.6 %), scenes whose shadow rays mostly reach the light lose (bunny +1.8 %, direct-lit bunny +2.7 %, testObj +0.9 %): not the default (profiles/r03 r3v10 against r3v9)
 #endif
+#ifndef PT_TUNE_WIDE_STREAM
+#define PT_TUNE_WIDE_STREAM 3  // bit 0: loads, bit 1: stores.  rays, queue slots and hit records pass through once: non-temporal loads and stores, so that they do not push the tree out of L2
+#endif
+#if PT_TUNE_WIDE_STREAM
+__device__ __forceinline__ float4 stream_load(const float4* p) {
+    const float4v v = __builtin_nontemporal_load((const float4v*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int stream_load(const int* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stream_store(float4* p, const float4 v) { __builtin_nontemporal_store(float4v{v.x, v.y, v.z, v.w}, (float4v*)p); }
+#if PT_TUNE_WIDE_STREAM & 1
+#define PT_STREAM_LOAD(P) stream_load(P)
+#else
+#define PT_STREAM_LOAD(P) (*(P))
+#endif
+#if PT_TUNE_WIDE_STREAM & 2
+#define PT_STREAM_STORE(P, V) stream_store((P), (V))
+#else
+#define PT_STREAM_STORE(P, V) (*(P) = (V))
+#endif
+#else
+#define PT_STREAM_LOAD(P) (*(P))
+#define PT_STREAM_STORE(P, V) (*(P) = (V))
+#endif
 #ifndef PT_TUNE_WIDE_SIGNMASK
 #define PT_TUNE_WIDE_SIGNMASK 1  // the slot test's hit mask from the sign bits of v - u (wide_hit_mask_fma_h)
 #endif
@@ -531,7 +555,7 @@ __device__ __forceinline__ void wide_body(
             int id = -1;                                                                   \
             if (PT_TUNE_WIDE_CARRY_ID) { if (bestSeq != 0x7fffffff) id = bestTri; }        \
             else if (bestSeq != 0x7fffffff) id = f2i(s.leafTris[3 * (size_t)bestSeq].w);   \
-            hits[raySlot] = make_float4(i2f(id), bestT, bestB, bestG);                     \
+            PT_STREAM_STORE(&hits[raySlot], make_float4(i2f(id), bestT, bestB, bestG));     \
         }                                                                                  \
         PT_RESET_LANE();                                                                   \
     } while (0)
@@ -638,7 +662,7 @@ __device__ __forceinline__ void wide_body(
                         slot = sh * q.regionSize + (j - prefix[sh]);
                     }
                     queueSlot = slot;
-                    raySlot = index ? (unsigned)index[slot] : slot;
+                    raySlot = index ? (unsigned)PT_STREAM_LOAD(&index[slot]) : slot;
                     fresh = true;
                 }
                 chunkBase += take;
@@ -709,7 +733,7 @@ __device__ __forceinline__ void wide_body(
                 bool slow = false;
                 if (fresh || adopt) {
                     const size_t rs = ANYHIT ? (size_t)queueSlot : (size_t)raySlot;  // shadow rays live in queue order
-                    const float4 r0 = rays[2 * rs], r1 = rays[2 * rs + 1];
+                    const float4 r0 = PT_STREAM_LOAD(&rays[2 * rs]), r1 = PT_STREAM_LOAD(&rays[2 * rs + 1]);
                     ox = r0.x; oy = r0.y; oz = r0.z; tMin = r0.w;
                     dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
                     // (an adopted ray qualified when its owner took it from the queue)
