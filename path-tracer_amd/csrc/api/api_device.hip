@@ -928,6 +928,7 @@ struct mipt_ctx {
     std::vector<int> tileKey;
     int nOwnedTiles = 0;
     size_t pbPixels = 0;
+    bool countersClean = false;  // pb.counters are all zero (k_fold_counters leaves them so at the end of a frame)
     // stats
     bool profiling = false, counting = false;
     unsigned long long* dTotals = nullptr;  // [0] ext rays [1] shadow rays [2..3] closest visits/tests [4..5] occluded
@@ -2071,7 +2072,7 @@ static int ensure_path_buffers(mipt_ctx* c, size_t cap, size_t nPix) {
     const size_t regionSize = regionWaves * 64, space = regionSize * kShards;  // >= cap
     const size_t oRays = take(2 * cap * f4), oHit = take(cap * f4), oMult = take(cap * f4), oCnst = take(cap * f4);
     const size_t oPend = take(cap * f4), oHm = take(cap * f4), oVP = take(cap * f4), oVN = take(cap * f4), oVT = take(cap * f4);
-    const size_t oContrib = take(cap * nl * f4), oOcc = take(cap * nl), oKs = take(nPix * 6 * f4), oPix = take(cap * 4);
+    const size_t oContrib = take(cap * nl * f4), oOcc = take(cap * nl), oKs = take(nPix * 6 * f4), oPix = take(nPix * 4);  // (pixel index: one per pixel slot, shared by the samples in flight)
     const size_t oRes = take(cap * f4);
     const size_t oQ0 = take(space * 4), oQ1 = take(space * 4), oQA = take(space * 4);
     const size_t oSh = take(2 * space * nl * f4), oShT = take(space * nl * 4), oCnt = take(kCounterWords * 4);
@@ -2085,6 +2086,7 @@ static int ensure_path_buffers(mipt_ctx* c, size_t cap, size_t nPix) {
         c->pb.capacity = 0; c->pbPixels = 0; return rc;
     }
     c->pbPixels = nPix;
+    c->countersClean = false;
     unsigned char* b = (unsigned char*)c->pathMem.p;
     PathBuffers& pb = c->pb;
     pb.capacity = cap; pb.nLights = nl; pb.regionSize = (unsigned)regionSize; pb.space = (unsigned)space;
@@ -2168,7 +2170,10 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
     for (int base = 0; base < nSamples; base += inFlight) {
         fp.sample = (unsigned)(rp->sample_offset + base);
         fp.samplesInFlight = (nSamples - base) < inFlight ? (nSamples - base) : inFlight;
-        HIP_TRY(hipMemsetAsync(pb.counters, 0, kCounterWords * 4, c->stream));
+        // the queue counters start at zero: k_fold_counters of the frame before left them so; a memset after a new
+        // allocation or a frame that did not reach its end
+        if (!c->countersClean) HIP_TRY(hipMemsetAsync(pb.counters, 0, kCounterWords * 4, c->stream));
+        c->countersClean = false;
         {
             Timer tm(c, 2);
             count_launch(c, 2);
@@ -2246,6 +2251,7 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
             launch_resolve_samples(c->stream, fp, pb);
         }
         launch_fold_counters(c->stream, pb.counters, itDone, c->dTotals);
+        c->countersClean = true;
         c->acc.launches_other++;
     }
     HIP_TRY(hipGetLastError());

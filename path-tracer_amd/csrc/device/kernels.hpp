@@ -128,7 +128,7 @@ void launch_shade_path(hipStream_t st, const DevScene& s, const FrameParams& fp,
 // rgb (16-byte aligned) -> 8-bit channels as Image::save converts them; out 4-byte aligned
 void launch_pack_rgb8(hipStream_t st, const float* rgb, size_t nValues, unsigned char* out);
 void launch_resolve_samples(hipStream_t st, const FrameParams& fp, const PathBuffers& pb);
-void launch_fold_counters(hipStream_t st, const unsigned* counters, int nIter, unsigned long long* totals);
+void launch_fold_counters(hipStream_t st, unsigned* counters, int nIter, unsigned long long* totals);
 // multi-GPU gather (kernels_tiles.hip): owned tiles of a W x H float3 frame <-> a dense buffer of nTiles x tileW x tileH x 3 floats
 void launch_pack_tiles(hipStream_t st, const float* rgb, const int* tiles, unsigned nTiles, int tileW, int tileH, int tilesX,
                        int width, int height, float* out);

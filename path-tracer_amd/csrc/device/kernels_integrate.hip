@@ -464,13 +464,18 @@ __global__ __launch_bounds__(kBlock) void k_shade_b_direct(DevScene s, FramePara
 }
 
 // one wavefront: lane = shard
-__global__ __launch_bounds__(64) void k_fold_counters(const unsigned* __restrict__ counters, int nIter, unsigned long long* totals) {
+// ... which also leaves the counters and cursors of the iterations the frame used at zero for the next frame (no 1.6-MB
+// memset per frame)
+__global__ __launch_bounds__(64) void k_fold_counters(unsigned* __restrict__ counters, int nIter, unsigned long long* totals) {
     const int s = threadIdx.x;
     unsigned long long e = 0, sh = 0;
     for (int it = 0; it < nIter; it++) {
         e += counters[counter_index(it, 0, s)];
         sh += counters[counter_index(it, 2, s)];
     }
+    const int nUsed = nIter + 2 < kMaxIter ? nIter + 2 : kMaxIter;  // shade(it) appends to the extension queue of it + 1
+    for (int it = 0; it < nUsed; it++)
+        for (int qu = 0; qu < kQueuesPerIter; qu++) counters[counter_index(it, qu, s)] = 0u;
     for (int off = 32; off > 0; off >>= 1) {
         e += __shfl_down(e, off);
         sh += __shfl_down(sh, off);
@@ -533,7 +538,7 @@ void launch_pack_rgb8(hipStream_t st, const float* rgb, size_t nValues, unsigned
 void launch_resolve_samples(hipStream_t st, const FrameParams& fp, const PathBuffers& pb) {
     hipLaunchKernelGGL(k_resolve_samples, dim3(grid_for(fp.nTilePaths)), dim3(kBlock), 0, st, fp, pb);
 }
-void launch_fold_counters(hipStream_t st, const unsigned* counters, int nIter, unsigned long long* totals) {
+void launch_fold_counters(hipStream_t st, unsigned* counters, int nIter, unsigned long long* totals) {
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, st, counters, nIter, totals);
 }
 
