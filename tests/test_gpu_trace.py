@@ -389,8 +389,9 @@ def test_rays_through_vertices_and_the_exact_walk_kernels_on_ordinary_rays(B, ob
         ref = orc.intersect(o, d)
         oref = orc.occluded(o, d, 1e-4, 2.0)
         assert (ref[0] >= 0).mean() > 0.5
-        # MIPT_DRAIN=1 (the default): lists of up to 4,096 rays are traced by k_trace_wide's own wavefronts as they finish
-        # (round 3), =0: by k_trace_slow in a launch of its own; twice per context, since the list must be back at rest
+        # MIPT_DRAIN=1 (the default): short lists (two entries per wavefront of the launch) are traced by k_trace_wide's own
+        # wavefronts as they finish, the rest by list-mode k_trace after the launch (round 3); =0: by k_trace_slow in a launch
+        # of its own; twice per context, since the list must be back at rest
         # (-1 everywhere) after every call
         for hand_back, drain in (("0", "1"), ("1", "1"), ("1", "0")):
             monkeypatch.setenv("MIPT_HAND_BACK_ALL", hand_back)
