@@ -295,3 +295,23 @@ def test_overlapped_and_serialised_bounces_give_the_same_frame(B, ob, sf):
     ctx.set_overlap(True)
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
     assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
+
+
+def test_fused_and_separate_traversal_launches_give_the_same_frame(B, ob, sf, monkeypatch):
+    """path mode traces the shadow rays of bounce k and the extension rays of bounce k+1 in ONE launch
+    (k_trace_wide_both); MIPT_FUSE=0 gives a launch per traversal, MIPT_FUSE_ORDER=shadow the other order of the two
+    queues inside the fused launch: the same frame bit for bit, Russian roulette bounces included, two lights"""
+    arrays = sf.load_scene_arrays("cornellbox-glass")
+    lights = ((3.0, 3.0, 3.0, 1000.0, 1000.0, 1000.0), (-1.5, 2.0, 2.5, 300.0, 500.0, 700.0))
+    cam = B.default_camera(160, 120)
+    frames = []
+    for env in ({}, {"MIPT_FUSE": "0"}, {"MIPT_FUSE_ORDER": "shadow"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        scene = sf.product_scene_from_mesh_arrays(*arrays, lights=lights)
+        ctx = B.Context(scene, device=0)
+        for k in env:
+            monkeypatch.delenv(k)
+        frames.append(ctx.render(cam, mode=B.MODE_PATH, spp=5, max_bounces=9, seed=3))
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
