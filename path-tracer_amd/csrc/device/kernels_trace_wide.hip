@@ -737,11 +737,13 @@ __device__ __forceinline__ void wide_body(
                     ox = r0.x; oy = r0.y; oz = r0.z; tMin = r0.w;
                     dx = r1.x; dy = r1.y; dz = r1.z; tMax = r1.w;
                     // (an adopted ray qualified when its owner took it from the queue)
-                    if (adopt || (!s.handBackAll && fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz})
 #if PT_TUNE_WIDE_PRECISE_HANDBACK
-                                  && mag_within(dx, PT_TUNE_WIDE_PRECISE_EXP, kDirHi) && mag_within(dy, PT_TUNE_WIDE_PRECISE_EXP, kDirHi) && mag_within(dz, PT_TUNE_WIDE_PRECISE_EXP, kDirHi)
+                    static_assert(PT_TUNE_WIDE_PRECISE_EXP >= kDirLo, "the hand-back bound lies inside fast_div_ok's");
+                    const bool qualifies = fast_div_ok_flat(ox, oy, oz, dx, dy, dz, PT_TUNE_WIDE_PRECISE_EXP);
+#else
+                    const bool qualifies = fast_div_ok(vec3{ox, oy, oz}, vec3{dx, dy, dz});
 #endif
-                                  )) {
+                    if (adopt | (!s.handBackAll & qualifies)) {
                         yx = 1.0f / dx; yy = 1.0f / dy; yz = 1.0f / dz;
 #if PT_TUNE_WIDE_FMA
                         ynx = yx * 0x1.ffffcp-1f; yny = yy * 0x1.ffffcp-1f; ynz = yz * 0x1.ffffcp-1f;

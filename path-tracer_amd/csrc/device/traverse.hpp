@@ -62,6 +62,22 @@ __device__ __forceinline__ bool fast_div_ok(const vec3 o, const vec3 d) {
            mag_within(d.y, kDirLo, kDirHi) && mag_within(d.z, kDirLo, kDirHi);
 }
 
+// the same predicate with a lower bound of its own for the direction components (2^dirLo <= |d| <= 2^kDirHi, dirLo >=
+// kDirLo), evaluated WITHOUT short-circuit branches: six range checks joined by bitwise ands are a dozen compares and scalar
+// ands, where the && chain is five nested branches on the execution mask (k_trace_wide's refill runs it for every ray)
+__device__ __forceinline__ bool fast_div_ok_flat(const float ox, const float oy, const float oz, const float dx, const float dy,
+                                                 const float dz, const int dirLo) {
+    const unsigned ex = ((unsigned)f2i(ox) >> 23) & 0xffu, ey = ((unsigned)f2i(oy) >> 23) & 0xffu, ez = ((unsigned)f2i(oz) >> 23) & 0xffu;
+    const unsigned fx = ((unsigned)f2i(dx) >> 23) & 0xffu, fy = ((unsigned)f2i(dy) >> 23) & 0xffu, fz = ((unsigned)f2i(dz) >> 23) & 0xffu;
+    const unsigned span = (unsigned)(kTameHi - kTameLo), lo = (unsigned)(127 + kTameLo);
+    const int okx = (int)(((unsigned)f2i(ox) << 1) == 0u) | (int)(ex - lo <= span);
+    const int oky = (int)(((unsigned)f2i(oy) << 1) == 0u) | (int)(ey - lo <= span);
+    const int okz = (int)(((unsigned)f2i(oz) << 1) == 0u) | (int)(ez - lo <= span);
+    const unsigned dspan = (unsigned)(kDirHi - dirLo), dlo = (unsigned)(127 + dirLo);
+    const int okd = (int)(fx - dlo <= dspan) & (int)(fy - dlo <= dspan) & (int)(fz - dlo <= dspan);
+    return (okx & oky & okz & okd) != 0;
+}
+
 // native vector types: loadable through address-space-qualified pointers (LDS / global), and the packed fp32 math
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
