@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void wide_body(
                     bool acc = tri_test(vec3{q0.x, q0.y, q0.z}, vec3{q1.x, q1.y, q1.z}, vec3{q2.x, q2.y, q2.z},
                                         vec3{ox, oy, oz}, vec3{dx, dy, dz}, tMin, tMax, t, be, ga);
                     // the reference keeps the FIRST of equal t's in depth-first order: smaller leafTris index wins
-                    acc = acc && (ANYHIT || t < bestT || (t == bestT && cur < bestSeq));
+                    acc = acc & (ANYHIT | (t < bestT) | ((t == bestT) & (cur < bestSeq)));  // (bitwise: compares and scalar ands, no nested branches)
                     if (acc) {  // provisionally the best; its leaf's exact box is tested at the end of this leaf phase
                         // a verified best that an unverified one replaces is lost if the latter fails: that ray is
                         // re-traced (see above), so nothing needs to be kept
