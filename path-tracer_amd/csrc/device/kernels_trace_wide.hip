@@ -245,6 +245,9 @@ __device__ __forceinline__ void stream_store(float4* p, const float4 v) { __buil
 #define PT_STREAM_LOAD(P) (*(P))
 #define PT_STREAM_STORE(P, V) (*(P) = (V))
 #endif
+#ifndef PT_TUNE_WIDE_FLAT_STACK
+#define PT_TUNE_WIDE_FLAT_STACK 1  // the stack steps of a visit with selects instead of nested branches (r3: closest-hit launch 3.72 -> 3.71 ms, any-hit 0.945 -> 0.936, four A/B pairs of four)
+#endif
 #ifndef PT_TUNE_WIDE_SIGNMASK
 #define PT_TUNE_WIDE_SIGNMASK 1  // the slot test's hit mask from the sign bits of v - u (wide_hit_mask_fma_h)
 #endif
@@ -888,6 +891,23 @@ __device__ __forceinline__ void wide_body(
                     g[0] = ((unsigned)f2i(meta.y) << 8) | (unsigned)lh;
                     ++groups;
                 }
+#if PT_TUNE_WIDE_FLAT_STACK
+                {   // the steps below with selects in place of the nested branches (one branch each is left, for the LDS write and
+                    // the LDS read)
+                    const bool push = (ih != 0) & (tos != 0u);
+                    if (push) stack[sp] = tos;
+                    sp += push ? kBlk : 0;
+                    tos = ih != 0 ? (((unsigned)f2i(meta.x) << 8) | (unsigned)ih) : tos;
+                    const unsigned e = tos, rest = e & (e - 1u);
+                    w = e != 0u ? (int)(e >> 8) + __builtin_ctz(e | 0x80000000u) : -1;
+                    const bool emptied = (rest & 255u) == 0u;  // (also when e is 0)
+                    const bool pop = (e != 0u) & emptied & (sp > bot);
+                    sp -= pop ? kBlk : 0;
+                    unsigned under = 0u;
+                    if (pop) under = stack[sp];
+                    tos = emptied ? under : rest;
+                }
+#else
                 if (ih != 0) {  // the hit children go on top of the stack as one entry
                     if (tos != 0u) { stack[sp] = tos; sp += kBlk; }
                     tos = ((unsigned)f2i(meta.x) << 8) | (unsigned)ih;
@@ -900,6 +920,7 @@ __device__ __forceinline__ void wide_body(
                         if (sp > bot) { sp -= kBlk; tos = stack[sp]; }
                     }
                 }
+#endif
             }
         }
 #else
