@@ -820,13 +820,15 @@ __device__ __forceinline__ void wide_body(
         }
         if (nEmpty == 64) continue;  // nothing else to do yet (the refill may have found rays: look again)
         // ---- visits: lanes with a node to visit and room for one more leaf group ----
+        // (the tail: shorter turns, work spreads sooner)
+        const int nBurst = (PT_TUNE_WIDE_TAIL_BURST > 0 && SHARE && exhausted) ? PT_TUNE_WIDE_TAIL_BURST
+                                                                               : (ANYHIT ? PT_TUNE_WIDE_BURST_ANYHIT : PT_TUNE_WIDE_BURST);
 #if PT_TUNE_WIDE_BURST_UNROLL
         PT_PRAGMA(unroll PT_TUNE_WIDE_BURST_UNROLL)
 #else
 #pragma unroll
 #endif
-        for (int b = 0; b < (ANYHIT ? PT_TUNE_WIDE_BURST_ANYHIT : PT_TUNE_WIDE_BURST); b++) {
-            if (PT_TUNE_WIDE_TAIL_BURST > 0 && SHARE && exhausted && b >= PT_TUNE_WIDE_TAIL_BURST) break;  // the tail: shorter turns, work spreads sooner
+        for (int b = 0; b < nBurst; b++) {
 #if PT_DIAG_UTIL == 1
             if (COUNT) { const unsigned long long ma = __ballot(w >= 0 && groups < kG); if (ma) { nv += (w >= 0 && groups < kG) ? 1u : 0u; nt += lane == 0 ? 64u : 0u; } }
 #endif
