@@ -1462,10 +1462,11 @@ int scene_create_impl(const mipt_scene_desc* d, const char* wide_cache_path, mip
             float f[28];
             memcpy(f, d->pos + (size_t)9 * t, 36);
             memcpy(f + 9, d->nrm + (size_t)9 * t, 36);
-            memcpy(f + 18, d->uv + (size_t)6 * t, 24);
             const int mid = d->mat_id[t];
-            memcpy(f + 24, &mid, 4);
-            f[25] = f[26] = f[27] = 0.0f;
+            memcpy(f + 18, &mid, 4);  // the first 80 B hold what every shaded hit reads, the texture coordinates follow
+            f[19] = 0.0f;
+            memcpy(f + 20, d->uv + (size_t)6 * t, 24);
+            f[26] = f[27] = 0.0f;
             memcpy(&s->triAttr[(size_t)ptd::kTriAttrF4 * t], f, sizeof f);
         }
         if (d->env_width > 0) s->env.assign(d->env_rgb, d->env_rgb + (size_t)3 * d->env_width * d->env_height);

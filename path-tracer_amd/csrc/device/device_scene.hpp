@@ -39,7 +39,8 @@
 //             reference's Cramer test (cs488.h:782-783), rounded once on the
 //             host exactly as the reference rounds them per test
 //   triAttr   8 x float4 per triangle (128 B = one cache line per shaded hit; 7 used), original order, for shading only:
-//               p0 p1 p2 n0 n1 n2 (18 floats) uv0 uv1 uv2 (6) bits(material id) pad
+//               p0 p1 p2 n0 n1 n2 (18 floats) bits(material id) pad | uv0 uv1 uv2 (6) pad: an untextured vertex reads the
+//               first five float4 only (shading.hpp: reconstruct_hit, hit_texcoord)
 //   materials 4 x float4 per material: {type, eta, Ns, bits(texel offset or -1)}
 //               {Kd.xyz, bits(texW)} {Ks.xyz, bits(texH)} {Ka.xyz, 0}
 //   texels    8-bit RGB, row 0 = top row of the file

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams f
                 const vec3 P = hi.P, N = hi.N;
                 if (m.type == MIPT_MAT_LAMBERTIAN) {
                     vec3 texture{1.0f, 1.0f, 1.0f};
-                    if (m.texOfs >= 0) texture = texture * fetch_texture(s, m, hi.T);
+                    if (m.texOfs >= 0) texture = texture * fetch_texture(s, m, hit_texcoord(s, tri, h.z, h.w));
                     const vec3 brdf = m.Kd / kPI;
                     for (int k = 0; k < nl; k++) {  // C:2287-2310
                         const float4 lp = s.lights[2 * k], lw = s.lights[2 * k + 1];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_a_direct(DevScene s, FramePara
                 P = hi.P;
                 if (m.type == MIPT_MAT_LAMBERTIAN) {
                     vec3 brdf = m.Kd / kPI;
-                    if (m.texOfs >= 0) brdf = brdf * fetch_texture(s, m, hi.T);
+                    if (m.texOfs >= 0) brdf = brdf * fetch_texture(s, m, hit_texcoord(s, tri, h.z, h.w));
                     for (int k = 0; k < nl; k++) {  // C:2409-2435
                         const float4 lp = s.lights[2 * k], lw = s.lights[2 * k + 1];
                         vec3 l = xyz(lp) - P;

@@ -336,7 +336,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve_hits(DevScene s, const float
         float* q = out + (size_t)10 * i;
         const int tri = f2i(h.x);
         if (tri >= 0) {
-            const HitInfo hi = reconstruct_hit(s, tri, h.y, h.z, h.w, vec3{r1.x, r1.y, r1.z});
+            HitInfo hi = reconstruct_hit(s, tri, h.y, h.z, h.w, vec3{r1.x, r1.y, r1.z});
+            hi.T = hit_texcoord(s, tri, h.z, h.w);
             q[0] = hi.t; q[1] = hi.P.x; q[2] = hi.P.y; q[3] = hi.P.z; q[4] = hi.N.x; q[5] = hi.N.y; q[6] = hi.N.z;
             q[7] = hi.T.x; q[8] = hi.T.y; q[9] = (float)hi.material;
         } else {

@@ -27,24 +27,33 @@ struct HitInfo {  // C:510-517
     int material;
 };
 
-// second half of raytraceTriangle, C:800-809
+// second half of raytraceTriangle, C:800-809.  The record's first five float4 hold everything but the texture
+// coordinates (device_scene.hpp): an untextured vertex gathers five 16-B pieces of its triangle's line, not seven; T is
+// filled in by hit_texcoord for the vertices whose material has a texture (and for mipt_trace's HitInfo output).
 __device__ __forceinline__ HitInfo reconstruct_hit(const DevScene& s, int tri, float t, float beta, float gamma,
                                                    const vec3 rayD) {
     const float4* a = s.triAttr + (size_t)kTriAttrF4 * tri;
-    const float4 q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3], q4 = a[4], q5 = a[5], q6 = a[6];
+    const float4 q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3], q4 = a[4];
     const vec3 p0{q0.x, q0.y, q0.z}, p1{q0.w, q1.x, q1.y}, p2{q1.z, q1.w, q2.x};
     const vec3 n0{q2.y, q2.z, q2.w}, n1{q3.x, q3.y, q3.z}, n2{q3.w, q4.x, q4.y};
-    const vec2 t0{q4.z, q4.w}, t1{q5.x, q5.y}, t2{q5.z, q5.w};
     const float alpha = 1.0f - beta - gamma;
     const vec3 phi{alpha, beta, gamma};
     HitInfo h;
     h.t = t;
-    h.material = f2i(q6.x);
+    h.material = f2i(q4.z);
     h.P = pt::mulcols(p0, p1, p2, phi);
     h.N = pt::mulcols(n0, n1, n2, phi);
-    h.T = pt::mulcols(t0, t1, t2, phi);
+    h.T = vec2{0.0f, 0.0f};
     if (pt::dot(h.N, rayD) > 0.0f) h.N = -h.N;
     return h;
+}
+// C:806: the interpolated texture coordinate of the same hit
+__device__ __forceinline__ vec2 hit_texcoord(const DevScene& s, int tri, float beta, float gamma) {
+    const float4* a = s.triAttr + (size_t)kTriAttrF4 * tri;
+    const float4 q5 = a[5], q6 = a[6];
+    const vec2 t0{q5.x, q5.y}, t1{q5.z, q5.w}, t2{q6.x, q6.y};
+    const float alpha = 1.0f - beta - gamma;
+    return pt::mulcols(t0, t1, t2, vec3{alpha, beta, gamma});
 }
 
 // Scene::eyeRay, C:2183-2197
