@@ -2246,8 +2246,14 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
         if (overlap && itDone > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->evOccluded[(size_t)itDone - 1], 0));
         if (rp->mode == MIPT_MODE_PATH) {
             Timer tm(c, 2);
-            count_launch(c, 2);
-            launch_shade_path(c->stream, c->ds, fp, pb, itDone, true);  // paths that ended at a Lambertian vertex of the last bounce
+            // paths that ended at a Lambertian vertex of the last bounce wait in the "fin" queue for their shadow rays -- except
+            // with one light, where the cap's paths are settled by k_resolve_samples (RES_PENDING) and only Russian roulette
+            // (bounces after the fifth, C:2311) fills that queue: with a cap of at most five bounces it is empty
+            const bool finEmpty = nl == 1 && !unbounded && fp.maxBounces <= 5;
+            if (!finEmpty) {
+                count_launch(c, 2);
+                launch_shade_path(c->stream, c->ds, fp, pb, itDone, true);
+            }
             count_launch(c, 2);
             launch_resolve_samples(c->stream, fp, pb);
         }

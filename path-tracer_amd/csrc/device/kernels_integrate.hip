@@ -51,7 +51,12 @@ __device__ __forceinline__ float4 pack(const vec3 v, float w) { return make_floa
 // Path mode keeps several samples of every pixel in flight (slot p = sample * nTilePaths + pixel slot), so a
 // finished path only RECORDS its radiance; k_resolve_samples adds the records to the AccumulationBuffer in sample
 // order afterwards, which keeps the float sums identical to the reference's sample-after-sample loop (C:2240-2241).
-enum : int { RES_NONE = 0, RES_ACCUMULATE = 1, RES_BACKGROUND = 2 };
+enum : int { RES_NONE = 0, RES_ACCUMULATE = 1, RES_BACKGROUND = 2,
+             // the path ended at a Lambertian vertex of the LAST bounce (the cap) in a scene with one light: the record holds
+             // constTerm, and the vertex' direct light (contrib[] / occ[], FLAG_FOLDED form) is added when the samples are
+             // resolved -- the same sum `finish_path(constTerm + L)` would have recorded (C:2316), without a pass of its own
+             // over those paths after the last shadow rays
+             RES_PENDING = 3 };
 __device__ __forceinline__ void finish_path(const PathBuffers& pb, unsigned p, const vec3 result) {
     pb.res[p] = make_float4(result.x, result.y, result.z, i2f(RES_ACCUMULATE));
 }
@@ -105,8 +110,17 @@ __global__ __launch_bounds__(kBlock) void k_resolve_samples(FrameParams fp, Path
         float ax = a[0], ay = a[1], az = a[2];
         bool touched = false;
         for (int sm = 0; sm < fp.samplesInFlight; sm++) {
-            const float4 r = pb.res[(size_t)sm * fp.nTilePaths + j];
-            const int kind = f2i(r.w);
+            float4 r = pb.res[(size_t)sm * fp.nTilePaths + j];
+            int kind = f2i(r.w);
+            if (kind == RES_PENDING) {
+                const size_t p = (size_t)sm * fp.nTilePaths + j;
+                const float4 c = pb.contrib[p];  // one light
+                vec3 L{0.0f, 0.0f, 0.0f};
+                if (!(f2i(c.w) && pb.occ[p])) L = L + xyz(c);  // pending_light(), C:2303-2309
+                const vec3 v = xyz(r) + L;                     // C:2316 with L already times multTerm (FLAG_FOLDED)
+                r.x = v.x; r.y = v.y; r.z = v.z;
+                kind = RES_ACCUMULATE;
+            }
             if (kind == RES_ACCUMULATE) {
                 ax += r.x; ay += r.y; az += r.z;
                 const float sc = (float)(fp.sample + (unsigned)sm + 1u);  // sampleCount++ precedes the sample's loop
@@ -263,7 +277,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams f
                     if (!done && it > 5) {  // C:2311-2314, no weight compensation
                         if (counter_rand(fp.seedHash, (unsigned)pix, sample, dim++) < .25f) done = true;
                     }
-                    if (done) {
+                    if (done && fold && capped) {
+                        pb.res[p] = pack(cnst, i2f(RES_PENDING));  // settled by k_resolve_samples, after the last shadow rays
+                    } else if (done) {
                         if (!fold) pb.mult[p] = pack(mult, eta);
                         pb.cnst[p] = pack(cnst, i2f(fold ? (FLAG_PEND_LAMBERT | FLAG_FOLDED) : FLAG_PEND_LAMBERT));
                         toFin = true;
