@@ -91,6 +91,6 @@ if "--traffic" in sys.argv:
                              "hbm_write_bytes_per_launch": o.get("hbm_write_bytes_per_launch", 0.0),
                              "hbm_bytes_per_launch": o["hbm_read_bytes_per_launch"] + o.get("hbm_write_bytes_per_launch", 0.0),
                              "launches": o["launches"], "l2_hit_rate": o.get("l2_hit_rate"),
-                             "source": "as above; averaged over ALL launches of k_shade_path in the run (the finals-only launch "
-                                       "of every frame included)"}
+                             "source": "as above; averaged over ALL launches of k_shade_path in the run (a finals-only launch is "
+                                       "among them only where a frame issues one: more than one light, or a cap above five bounces)"}
     json.dump(t, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
