@@ -51,6 +51,16 @@ __device__ __forceinline__ float4 pack(const vec3 v, float w) { return make_floa
 // Path mode keeps several samples of every pixel in flight (slot p = sample * nTilePaths + pixel slot), so a
 // finished path only RECORDS its radiance; k_resolve_samples adds the records to the AccumulationBuffer in sample
 // order afterwards, which keeps the float sums identical to the reference's sample-after-sample loop (C:2240-2241).
+#ifndef PT_TUNE_SAMPLE_MINOR
+#define PT_TUNE_SAMPLE_MINOR 1  // 1: slot p = pixel slot * samplesInFlight + sample in flight (the samples of a pixel in adjacent lanes); 0: sample * nTilePaths + pixel slot
+#endif
+__device__ __forceinline__ unsigned slot_of(const FrameParams& fp, unsigned pixelSlot, unsigned sm) {
+    return PT_TUNE_SAMPLE_MINOR ? pixelSlot * (unsigned)fp.samplesInFlight + sm : sm * fp.nTilePaths + pixelSlot;
+}
+__device__ __forceinline__ void slot_split(const FrameParams& fp, unsigned p, unsigned& pixelSlot, unsigned& sm) {
+    if (PT_TUNE_SAMPLE_MINOR) { pixelSlot = p / (unsigned)fp.samplesInFlight; sm = p - pixelSlot * (unsigned)fp.samplesInFlight; }
+    else { sm = p / fp.nTilePaths; pixelSlot = p - sm * fp.nTilePaths; }
+}
 enum : int { RES_NONE = 0, RES_ACCUMULATE = 1, RES_BACKGROUND = 2,
              // the path ended at a Lambertian vertex of the LAST bounce (the cap) in a scene with one light: the record holds
              // constTerm, and the vertex' direct light (contrib[] / occ[], FLAG_FOLDED form) is added when the samples are
@@ -73,7 +83,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(CameraDev cam, FrameParams 
         bool valid = p < n;
         int pix = -1;
         if (valid) {
-            const unsigned j = p % fp.nTilePaths;  // pixel slot; p / nTilePaths is the sample in flight
+            unsigned j, sm;  // pixel slot, sample in flight
+            slot_split(fp, p, j, sm);
             const unsigned k = j / tilePix, r = j % tilePix;
             const unsigned blk = r >> 6, lane = r & 63u;  // 8x8 pixel block per wavefront
             const unsigned bpr = (unsigned)fp.tileW >> 3;
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(CameraDev cam, FrameParams 
                 pb.rays[2 * (size_t)p] = pack(o, 0.0f);
                 pb.rays[2 * (size_t)p + 1] = pack(d, kFltMax);
             }
-            if (p < fp.nTilePaths) pb.pixel[p] = pix;  // one entry per pixel slot: the samples in flight share it
+            if (sm == 0) pb.pixel[j] = pix;  // one entry per pixel slot: the samples in flight share it
             // (res[p] needs no initial value: every path that starts writes it exactly once -- a miss, a capped or
             // light-hitting vertex, or the pass over the paths that ended at a Lambertian vertex -- before
             // k_resolve_samples reads it, and slots without a pixel are skipped there)
@@ -101,6 +112,67 @@ __global__ __launch_bounds__(kBlock) void k_generate(CameraDev cam, FrameParams 
 }
 
 // AccumulationBuffer += result; FrameBuffer = Accum / sampleCount, sample after sample (C:2232, C:2240-2244)
+__device__ __forceinline__ float4 settled_record(const PathBuffers& pb, size_t p) {
+    float4 r = pb.res[p];
+    if (f2i(r.w) == RES_PENDING) {
+        const float4 c = pb.contrib[p];  // one light
+        vec3 L{0.0f, 0.0f, 0.0f};
+        if (!(f2i(c.w) && pb.occ[p])) L = L + xyz(c);  // pending_light(), C:2303-2309
+        const vec3 v = xyz(r) + L;                     // C:2316 with L already times multTerm (FLAG_FOLDED)
+        r = make_float4(v.x, v.y, v.z, i2f(RES_ACCUMULATE));
+    }
+    return r;
+}
+#if PT_TUNE_SAMPLE_MINOR
+// The samples in flight of a pixel lie side by side (slot_of), 16 B each, and a pixel's sum runs over them in order: a block
+// fetches the records of its 256 pixels, kResChunk samples at a time, with every lane on the next 16 B of memory (a pixel's
+// chunk is one 128-B line), settles the pending ones there, and hands them to the pixels' threads through LDS (component
+// arrays, kResChunk + 1 floats per pixel: the threads' walks hit distinct banks).  One thread per pixel reading its own
+// 16-B records would fetch every line eight times over.
+constexpr int kResChunk = 8;
+__global__ __launch_bounds__(kBlock) void k_resolve_samples(FrameParams fp, PathBuffers pb) {
+    constexpr int kRow = kResChunk + 1;
+    __shared__ float lx[kBlock * kRow], ly[kBlock * kRow], lz[kBlock * kRow];
+    __shared__ int lk[kBlock * kRow];
+    const unsigned S = (unsigned)fp.samplesInFlight, t = threadIdx.x;
+    for (unsigned jBase = blockIdx.x * kBlock; jBase < fp.nTilePaths; jBase += gridDim.x * kBlock) {
+        const unsigned j = jBase + t;
+        const int pix = j < fp.nTilePaths ? pb.pixel[j] : -1;
+        float* a = fp.accum + (size_t)3 * (pix < 0 ? 0 : pix);
+        float ax = 0.0f, ay = 0.0f, az = 0.0f, qx = 0.0f, qy = 0.0f, qz = 0.0f;
+        if (pix >= 0) { ax = a[0]; ay = a[1]; az = a[2]; }
+        bool touched = false, shown = false;
+        for (unsigned c0 = 0; c0 < S; c0 += kResChunk) {
+            const unsigned cc = (S - c0) < (unsigned)kResChunk ? (S - c0) : (unsigned)kResChunk;
+            __syncthreads();  // the chunk before has been consumed
+            for (unsigned e = t; e < kBlock * cc; e += kBlock) {
+                const unsigned jj = e / cc, sl = e - jj * cc;
+                float4 r = make_float4(0.0f, 0.0f, 0.0f, i2f(RES_NONE));
+                if (jBase + jj < fp.nTilePaths) r = settled_record(pb, (size_t)(jBase + jj) * S + c0 + sl);
+                lx[jj * kRow + sl] = r.x; ly[jj * kRow + sl] = r.y; lz[jj * kRow + sl] = r.z; lk[jj * kRow + sl] = f2i(r.w);
+            }
+            __syncthreads();
+            if (pix >= 0) {
+                for (unsigned sl = 0; sl < cc; sl++) {
+                    const int kind = lk[t * kRow + sl];
+                    const float rx = lx[t * kRow + sl], ry = ly[t * kRow + sl], rz = lz[t * kRow + sl];
+                    if (kind == RES_ACCUMULATE) {
+                        ax += rx; ay += ry; az += rz;
+                        const float sc = (float)(fp.sample + c0 + sl + 1u);  // sampleCount++ precedes the sample's loop
+                        qx = ax / sc; qy = ay / sc; qz = az / sc;           // (the frame buffer keeps the last one)
+                        touched = true; shown = true;
+                    } else if (kind == RES_BACKGROUND) {
+                        qx = rx; qy = ry; qz = rz;
+                        shown = true;
+                    }
+                }
+            }
+        }
+        if (touched) { a[0] = ax; a[1] = ay; a[2] = az; }
+        if (shown) { float* q = fp.rgb + (size_t)3 * pix; q[0] = qx; q[1] = qy; q[2] = qz; }
+    }
+}
+#else
 __global__ __launch_bounds__(kBlock) void k_resolve_samples(FrameParams fp, PathBuffers pb) {
     for (unsigned j = blockIdx.x * kBlock + threadIdx.x; j < fp.nTilePaths; j += gridDim.x * kBlock) {
         const int pix = pb.pixel[j];
@@ -110,17 +182,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve_samples(FrameParams fp, Path
         float ax = a[0], ay = a[1], az = a[2];
         bool touched = false;
         for (int sm = 0; sm < fp.samplesInFlight; sm++) {
-            float4 r = pb.res[(size_t)sm * fp.nTilePaths + j];
-            int kind = f2i(r.w);
-            if (kind == RES_PENDING) {
-                const size_t p = (size_t)sm * fp.nTilePaths + j;
-                const float4 c = pb.contrib[p];  // one light
-                vec3 L{0.0f, 0.0f, 0.0f};
-                if (!(f2i(c.w) && pb.occ[p])) L = L + xyz(c);  // pending_light(), C:2303-2309
-                const vec3 v = xyz(r) + L;                     // C:2316 with L already times multTerm (FLAG_FOLDED)
-                r.x = v.x; r.y = v.y; r.z = v.z;
-                kind = RES_ACCUMULATE;
-            }
+            const float4 r = settled_record(pb, slot_of(fp, j, (unsigned)sm));
+            const int kind = f2i(r.w);
             if (kind == RES_ACCUMULATE) {
                 ax += r.x; ay += r.y; az += r.z;
                 const float sc = (float)(fp.sample + (unsigned)sm + 1u);  // sampleCount++ precedes the sample's loop
@@ -133,6 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_samples(FrameParams fp, Path
         if (touched) { a[0] = ax; a[1] = ay; a[2] = az; }
     }
 }
+#endif
 
 // emit the next extension ray of path p
 __device__ __forceinline__ void emit_extension(const PathBuffers& pb, unsigned p, const vec3 P, float tmin, const vec3 dir) {
@@ -270,8 +334,9 @@ __global__ __launch_bounds__(kBlock) void k_shade_path(DevScene s, FrameParams f
                             pb.shTarget[sl] = (int)((size_t)p * nl + k);
                         }
                     }
-                    const unsigned inFlight = p / fp.nTilePaths;  // which of the samples in flight this path is
-                    const int pix = pb.pixel[p - inFlight * fp.nTilePaths];
+                    unsigned pixelSlot, inFlight;  // inFlight: which of the samples in flight this path is
+                    slot_split(fp, p, pixelSlot, inFlight);
+                    const int pix = pb.pixel[pixelSlot];
                     const unsigned sample = fp.sample + inFlight;
                     bool done = capped;
                     if (!done && it > 5) {  // C:2311-2314, no weight compensation
