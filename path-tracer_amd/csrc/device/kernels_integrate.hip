@@ -48,7 +48,8 @@ __device__ __forceinline__ bool slot_live(const unsigned* shard0, unsigned regio
 __device__ __forceinline__ vec3 xyz(const float4 v) { return vec3{v.x, v.y, v.z}; }
 __device__ __forceinline__ float4 pack(const vec3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 
-// Path mode keeps several samples of every pixel in flight (slot p = sample * nTilePaths + pixel slot), so a
+// Path mode keeps several samples of every pixel in flight (slot p = pixel slot * samplesInFlight + sample in flight, slot_of:
+// the samples of a pixel sit in adjacent lanes -- they start with the same ray, C:2183-2197 has no jitter), so a
 // finished path only RECORDS its radiance; k_resolve_samples adds the records to the AccumulationBuffer in sample
 // order afterwards, which keeps the float sums identical to the reference's sample-after-sample loop (C:2240-2241).
 #ifndef PT_TUNE_SAMPLE_MINOR
