@@ -2136,10 +2136,13 @@ int mipt_render_device(mipt_ctx* c, const mipt_camera* cam, const mipt_render_pa
     const size_t nPix = (size_t)c->nOwnedTiles * tileW * tileH;  // pixel slots of this partition
     if (nPix > ((size_t)1 << 25)) return fail(MIPT_ERR_LIMIT, "more than 2^25 pixels in one partition");
     // path mode traces several samples of every pixel together: bigger queues keep the persistent traversal
-    // wavefronts fed (HBM is large: ~250 B per path slot, at most 2^25 slots = 8 GB)
+    // wavefronts fed, and more samples of a pixel side by side put whole wavefronts on one pixel (HBM is large: ~257 B per path
+    // slot, at most 2^27 slots = 34 GB; up to r3v23 2^25)
     int inFlight = 1;
     if (rp->mode == MIPT_MODE_PATH) {
-        const size_t fit = ((size_t)1 << 25) / nPix;
+        size_t slotsLog2 = 27;  // 2^27 path slots = 34 GB of path state of the GPU's 288 GB (MIPT_PATH_SLOTS_LOG2: 20 .. 28)
+        if (const char* e = getenv("MIPT_PATH_SLOTS_LOG2")) { const long v = atol(e); if (v >= 20 && v <= 28) slotsLog2 = (size_t)v; }
+        const size_t fit = ((size_t)1 << slotsLog2) / nPix;
         inFlight = (int)(fit < 1 ? 1 : (fit > (size_t)rp->spp ? (size_t)rp->spp : fit));
     }
     const size_t cap = nPix * (size_t)inFlight;
