@@ -315,3 +315,35 @@ def test_fused_and_separate_traversal_launches_give_the_same_frame(B, ob, sf, mo
         frames.append(ctx.render(cam, mode=B.MODE_PATH, spp=5, max_bounces=9, seed=3))
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
     assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
+
+
+@pytest.mark.parametrize("name,lights,bounces", [
+    ("cornellbox-glass", None, 4),   # one light, a cap of four bounces: the cap's paths are settled by k_resolve_samples, no "fin" pass
+    ("cornellbox-glass", None, 9),   # one light, Russian roulette after the fifth bounce: both ways of settling a path in one frame
+    ("cornellbox", ((3.0, 3.0, 3.0, 1000.0, 1000.0, 1000.0), (-1.5, 2.0, 2.5, 300.0, 500.0, 700.0)), 4),  # two lights: the "fin" queue only
+])
+def test_frame_does_not_depend_on_the_samples_in_flight(B, ob, sf, monkeypatch, name, lights, bounces):
+    """How many samples of a pixel are traced together (min(spp, path slots / pixel slots), MIPT_PATH_SLOTS_LOG2 read by
+    every render call) decides which path sits in which lane and in how many rounds k_resolve_samples sums a pixel --
+    never a bit of the frame: 70 spp of a 160x120 frame with 70 samples in flight, in rounds of 45 + 25, and as 64 + 6
+    progressive calls"""
+    arrays = sf.load_scene_arrays(name)
+    scene = sf.product_scene_from_mesh_arrays(*arrays, lights=lights or sf.DEFAULT_LIGHT)
+    ctx = B.Context(scene, device=0)
+    cam = B.default_camera(160, 120)  # 19,200 pixels in 64x8 tiles: 23,040 pixel slots
+    frames = []
+    for log2 in (None, "20", "28"):   # 2^27 / 23,040 >= 70 samples in flight; 2^20: 45 -> rounds of 45 + 25; 2^28: as the default
+        if log2:
+            monkeypatch.setenv("MIPT_PATH_SLOTS_LOG2", log2)
+        frames.append(ctx.render(cam, mode=B.MODE_PATH, spp=70, max_bounces=bounces, seed=11))
+        if log2:
+            monkeypatch.delenv("MIPT_PATH_SLOTS_LOG2")
+    n = 120 * 160 * 3 * 4
+    acc, rgb = ctx.buffer_alloc(n), ctx.buffer_alloc(n)
+    for off, k in ((0, 64), (64, 6)):
+        ctx.render_device(cam, B.RenderParams(B.MODE_PATH, k, off, bounces, 11, 0, 1, 0, 0), acc, rgb)
+    frames.append(ctx.buffer_download(rgb, (120, 160, 3)))
+    ctx.buffer_free(acc)
+    ctx.buffer_free(rgb)
+    for f in frames[1:]:
+        assert np.array_equal(frames[0].view(np.uint32), f.view(np.uint32))
